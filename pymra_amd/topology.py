@@ -1,0 +1,367 @@
+"""Host-side tree builder: knots, partitions and the leaf-ordered row layout.
+
+Pure index arithmetic (NumPy, host).  It replays the *rules* of the reference's
+recursive constructor so that the same inputs and the same global NumPy RNG state
+give the same tree:
+
+* resolution / fan-out defaults and the M clip ......... pyMRA/MRATree.py:27-59
+* leaf test and early leaves .............................. pyMRA/MRANode.py:34-45
+* knot choice: 1-D nearest-rank quantiles, 2-D random
+  draw (global RNG, DFS pre-order) or KMeans ............ pyMRA/MRANode.py:179-205
+* candidate bookkeeping ("notKnots") ...................... pyMRA/MRANode.py:53, 83
+* partition: quadrants / terciles / knot-boundary / KMeans  pyMRA/MRANode.py:213-242, 289-340
+
+Differences in mechanism (not in result): membership is tracked by global row index
+instead of by coordinate value (the reference uses numpy_indexed.contains on the
+coordinates, which is the same thing for distinct locations), and the output is a flat,
+device-friendly description instead of a graph of Python objects:
+
+* every node's rows are one contiguous range of a *permuted, padded* row order
+  (depth-first leaf order; each leaf - and each group of rows that a partition drops,
+  see ``orphans`` - is padded to a multiple of ``ROW_ALIGN`` rows with phantom rows),
+* nodes are numbered level by level (``level_ptr``), children are contiguous.
+
+No reference code is imported or needed here.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+logger = logging.getLogger("pyMRA.MRATree")
+
+ROW_ALIGN = 16          # MFMA f64 tile height: every leaf row range is a multiple of this
+COL_ALIGN = 16          # MFMA f64 tile width: every per-level knot block is padded to this
+
+
+# ----------------------------------------------------------------------------------------
+#  M / J / critDepth resolution (pyMRA/MRATree.py:27-59)
+# ----------------------------------------------------------------------------------------
+def resolve_tree_shape(N: int, d: int, r: int, M: int = -1, J: int = -1):
+    """Return (M, J) exactly as the reference constructor resolves them.
+
+    J<0: 2-D -> 4; 1-D -> the reference evaluates ``self.J == r+1`` (a comparison on an
+    attribute that does not exist) and raises AttributeError (MRATree.py:31-33); we raise
+    the same exception type with a readable message.
+    maxM = int(log(N*J/r + 1)/log(J)) - 1 (MRATree.py:41-43); M<0 -> maxM; M>maxM -> clip
+    with a warning (MRATree.py:44-50).
+    """
+    if J < 0:
+        if d == 2:
+            J = 4
+        else:
+            raise AttributeError("'MRATree' object has no attribute 'J' "
+                                 "(pass J explicitly for %d-D locations)" % d)
+    num = np.log(N * J / r + 1)
+    denom = np.log(J)
+    if denom == 0:
+        raise OverflowError("cannot convert float infinity to integer")   # J == 1, as reference
+    maxM = int(num / denom) - 1
+    if M < 0:
+        M = maxM
+    elif M > maxM:
+        logger.warning("The number of resolutions M=%d you requested is to large for your "
+                       "grid. Setting M:=%d" % (M, maxM))
+        M = maxM
+    return int(M), int(J)
+
+
+# ----------------------------------------------------------------------------------------
+#  recursive replay
+# ----------------------------------------------------------------------------------------
+@dataclass
+class _TNode:
+    ident: str
+    level: int
+    rows: np.ndarray                 # global row indices, ascending (== reference's locs order)
+    knots: np.ndarray                # global row indices of the knots, ascending
+    leaf: bool
+    children: List["_TNode"] = field(default_factory=list)
+    child_local: List[np.ndarray] = field(default_factory=list)   # reference's inds[chID]
+
+
+def _nearest_rank_percentile(sorted_vals: np.ndarray, q: float) -> float:
+    return float(np.percentile(sorted_vals, q, method="nearest"))
+
+
+def _knots_1d(coords: np.ndarray, rows: np.ndarray, cand: np.ndarray, r: int) -> np.ndarray:
+    """Quantile knots in 1-D (MRANode.py:181-187): the r interior nearest-rank percentiles
+    of the candidate coordinates; a row is a knot when its coordinate equals one of them
+    (so repeated percentiles give fewer than r knots)."""
+    c1 = coords[cand, 0]
+    vals = [np.percentile(c1, 100.0 * i / (r + 1), method="nearest") for i in range(r + 2)][1:-1]
+    mask = np.isin(coords[rows, 0], np.asarray(vals))
+    return rows[mask]
+
+
+def _knots_kmeans(coords: np.ndarray, rows: np.ndarray, cand: np.ndarray, r: int) -> np.ndarray:
+    """Small-node knots (MRANode.py:195-201): KMeans(r, random_state=0) on the candidates,
+    then the candidate nearest to each centroid (first minimum)."""
+    from sklearn.cluster import KMeans
+    from scipy.spatial.distance import cdist
+    pts = coords[cand]
+    km = KMeans(n_clusters=r, random_state=0).fit(pts)
+    D = cdist(pts, km.cluster_centers_)
+    picked = np.unique(cand[np.argmin(D, axis=0)])
+    return picked
+
+
+def _splits_geometric(coords: np.ndarray, rows: np.ndarray) -> List[np.ndarray]:
+    """Partition of a node with more than 100 rows (MRANode.py:213-242), as *local* index
+    arrays.  1-D: strict terciles about np.percentile(.,(33,66)) - rows equal to a percentile
+    belong to no child.  2-D: quadrants about the coordinate means, order (<=,<=),(<=,>),
+    (>,<=),(>,>)."""
+    X = coords[rows]
+    if X.shape[1] == 1:
+        p = np.percentile(X, (33, 66))
+        x = X[:, 0]
+        return [np.where(x < p[0])[0],
+                np.where(np.logical_and(x > p[0], x < p[1]))[0],
+                np.where(x > p[1])[0]]
+    m = np.mean(X, axis=0)
+    lx = X[:, 0] <= m[0]
+    ly = X[:, 1] <= m[1]
+    return [np.where(lx & ly)[0], np.where(lx & ~ly)[0], np.where(~lx & ly)[0], np.where(~lx & ~ly)[0]]
+
+
+def _splits_small(coords: np.ndarray, rows: np.ndarray, knots: np.ndarray, newcand: np.ndarray,
+                  Jeff: int) -> List[np.ndarray]:
+    """Partition of a node with at most 100 rows (MRANode.py:289-340), local index arrays.
+
+    1-D with Jeff == #knots+1 and enough rows: cut at the knots (each knot starts the next
+    child).  Otherwise KMeans(min(Jeff, #newcand), random_state=0) on the remaining candidates;
+    every other row of the node (own and ancestors' knots) joins the nearest cluster centre;
+    empty clusters are skipped; 1-D children are ordered by their first row."""
+    N = len(rows)
+    klocal = np.searchsorted(rows, knots)
+    rk = len(klocal)
+    if Jeff == rk + 1 and coords.shape[1] == 1 and N >= Jeff + rk:
+        return [a for a in np.split(np.arange(N), klocal)]
+    from sklearn.cluster import KMeans
+    from scipy.spatial.distance import cdist
+    nk_local = np.searchsorted(rows, newcand)
+    pts = coords[newcand]
+    ncl = min(Jeff, len(newcand))
+    km = KMeans(n_clusters=ncl, random_state=0).fit(pts)
+    labels = km.labels_
+    other_local = np.setdiff1d(np.arange(N), nk_local)
+    out = []
+    if len(other_local):
+        D = cdist(coords[rows[other_local]], km.cluster_centers_)
+        olab = np.argmin(D, axis=1)
+    else:
+        olab = np.zeros(0, dtype=int)
+    for j in range(Jeff):
+        inds = np.sort(np.hstack((other_local[olab == j], nk_local[labels == j]))).astype(np.int64)
+        if len(inds):
+            out.append(inds)
+    if coords.shape[1] == 1:
+        out = sorted(out, key=lambda a: np.min(a))
+    return out
+
+
+def _grow(coords, rows, cand, levels_left, level, ident, r, J, flat: list) -> _TNode:
+    leaf = (levels_left == 0)
+    n_c = len(cand)
+    splitting = (not leaf) and n_c > max(r, J)
+    if splitting:
+        if coords.shape[1] == 1:
+            knots = _knots_1d(coords, rows, cand, r)
+        elif n_c > 1e2:
+            # MRANode.py:191-193: consumes the *global* NumPy RNG, in DFS pre-order
+            pick = np.random.choice(np.arange(n_c), size=r, replace=False)
+            knots = np.sort(cand[pick])
+        else:
+            knots = _knots_kmeans(coords, rows, cand, r)
+    else:
+        knots = cand
+        leaf = True
+    node = _TNode(ident, level, rows, knots, leaf)
+    flat.append(node)
+    if splitting:
+        newcand = np.setdiff1d(cand, knots, assume_unique=True)
+        Jeff = min(J, len(newcand))
+        if len(rows) > 1e2:
+            parts = _splits_geometric(coords, rows)
+        else:
+            parts = _splits_small(coords, rows, knots, newcand, Jeff)
+        is_new = np.zeros(0, dtype=bool)
+        for j, loc_idx in enumerate(parts):
+            ch_rows = rows[loc_idx]
+            ch_cand = np.intersect1d(ch_rows, newcand, assume_unique=True)
+            node.child_local.append(np.asarray(loc_idx, dtype=np.int64))
+            node.children.append(_grow(coords, ch_rows, ch_cand, levels_left - 1, level + 1,
+                                       ident + str(j + 1), r, J, flat))
+    return node
+
+
+# ----------------------------------------------------------------------------------------
+#  flat, padded, leaf-ordered description
+# ----------------------------------------------------------------------------------------
+@dataclass
+class Topology:
+    """Flat description of one MRA tree (all arrays host NumPy).
+
+    Row space: ``P`` padded rows in depth-first leaf order; ``perm[p]`` is the caller's row
+    index of padded row p, or -1 for a phantom (padding) row.  ``src[p]`` is a valid caller
+    row for *every* p (phantoms copy a real row of the same leaf so that kernel evaluations
+    stay finite; they are never observed and never reported).
+
+    Nodes are numbered level by level: level m owns nodes ``level_ptr[m]:level_ptr[m+1]``.
+    """
+    N: int
+    d: int
+    M: int
+    J: int
+    r: int
+    P: int
+    perm: np.ndarray            # int64[P]
+    src: np.ndarray             # int64[P]
+    in_leaf: np.ndarray         # bool[P]  real row that belongs to some leaf (else: orphan/phantom)
+    n_nodes: int
+    n_levels: int               # deepest level + 1
+    level_ptr: np.ndarray       # int64[n_levels+1]
+    node_level: np.ndarray      # int32[n]
+    node_row0: np.ndarray       # int64[n]
+    node_row1: np.ndarray       # int64[n]   (padded range end)
+    node_leaf: np.ndarray       # bool[n]
+    node_parent: np.ndarray     # int32[n]   (-1 root)
+    child_ptr: np.ndarray       # int32[n+1] children are nodes child_ptr[i]..child_ptr[i+1]-1 of child_list
+    child_list: np.ndarray      # int32[.]
+    knot_ptr: np.ndarray        # int64[n+1]
+    knot_rows: np.ndarray       # int64[.]   padded-row positions of each node's knots, in the
+                                #            reference's column order (ascending caller index)
+    node_ident: List[str]
+    cw: np.ndarray              # int32[n_levels] knot-block width of the NON-LEAF nodes of a level,
+                                #                 padded to COL_ALIGN (0 if the level has none)
+    order_preorder: np.ndarray  # int32[n] node numbers in the reference's construction order
+
+    def rank(self, i: int) -> int:
+        return int(self.knot_ptr[i + 1] - self.knot_ptr[i])
+
+    @property
+    def nodes_per_level(self):
+        return np.diff(self.level_ptr)
+
+
+def build_topology(locs: np.ndarray, r: int, M: int, J: int) -> Topology:
+    """Replay the reference's tree construction for ``locs`` (N x d, d in {1,2}).
+
+    M and J must already be resolved (``resolve_tree_shape``).  Consumes the global NumPy
+    RNG exactly like the reference does (one ``np.random.choice`` per 2-D node with more
+    than 100 candidates, depth-first pre-order)."""
+    coords = np.ascontiguousarray(np.asarray(locs, dtype=np.float64))
+    if coords.ndim == 1:
+        coords = coords.reshape(-1, 1)
+    N, d = coords.shape
+    flat: List[_TNode] = []
+    all_rows = np.arange(N, dtype=np.int64)
+    root = _grow(coords, all_rows, all_rows, M, 0, "r", r, J, flat)
+
+    # ---- leaf-ordered padded row layout --------------------------------------------------
+    perm_chunks: List[np.ndarray] = []
+    src_chunks: List[np.ndarray] = []
+    inleaf_chunks: List[np.ndarray] = []
+    cursor = [0]
+    span = {}
+
+    def _emit(real_rows: np.ndarray, is_leaf_rows: bool):
+        n = len(real_rows)
+        npad = (-n) % ROW_ALIGN
+        p = np.concatenate([real_rows, np.full(npad, -1, dtype=np.int64)])
+        filler = real_rows[0] if n else 0
+        s = np.concatenate([real_rows, np.full(npad, filler, dtype=np.int64)])
+        perm_chunks.append(p)
+        src_chunks.append(s)
+        fl = np.zeros(n + npad, dtype=bool)
+        fl[:n] = is_leaf_rows
+        inleaf_chunks.append(fl)
+        cursor[0] += n + npad
+
+    def _layout(nd: _TNode):
+        start = cursor[0]
+        if nd.leaf:
+            _emit(nd.rows, True)
+        else:
+            covered = np.zeros(len(nd.rows), dtype=bool)
+            for ch, li in zip(nd.children, nd.child_local):
+                covered[li] = True
+                _layout(ch)
+            orphans = nd.rows[~covered]
+            if len(orphans):
+                _emit(orphans, False)
+        span[id(nd)] = (start, cursor[0])
+
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    _layout(root)
+    P = cursor[0]
+    perm = np.concatenate(perm_chunks) if perm_chunks else np.zeros(0, dtype=np.int64)
+    src = np.concatenate(src_chunks) if src_chunks else np.zeros(0, dtype=np.int64)
+    in_leaf = np.concatenate(inleaf_chunks) if inleaf_chunks else np.zeros(0, dtype=bool)
+    pos_of = np.full(N, -1, dtype=np.int64)
+    real = perm >= 0
+    pos_of[perm[real]] = np.nonzero(real)[0]
+
+    # ---- level-major node numbering (children of a node stay contiguous) --------------------
+    n_nodes = len(flat)
+    n_levels = max(nd.level for nd in flat) + 1
+    by_level: List[List[_TNode]] = [[] for _ in range(n_levels)]
+    # breadth-first keeps siblings adjacent and parents ordered
+    frontier = [root]
+    while frontier:
+        nxt = []
+        for nd in frontier:
+            by_level[nd.level].append(nd)
+            nxt.extend(nd.children)
+        frontier = nxt
+    number = {}
+    k = 0
+    level_ptr = np.zeros(n_levels + 1, dtype=np.int64)
+    for m in range(n_levels):
+        for nd in by_level[m]:
+            number[id(nd)] = k
+            k += 1
+        level_ptr[m + 1] = k
+
+    node_level = np.zeros(n_nodes, dtype=np.int32)
+    node_row0 = np.zeros(n_nodes, dtype=np.int64)
+    node_row1 = np.zeros(n_nodes, dtype=np.int64)
+    node_leaf = np.zeros(n_nodes, dtype=bool)
+    node_parent = np.full(n_nodes, -1, dtype=np.int32)
+    child_ptr = np.zeros(n_nodes + 1, dtype=np.int32)
+    knot_ptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    idents = [""] * n_nodes
+    child_list: List[int] = []
+    knot_chunks: List[np.ndarray] = [None] * n_nodes
+    ordered = [nd for m in range(n_levels) for nd in by_level[m]]
+    for i, nd in enumerate(ordered):
+        node_level[i] = nd.level
+        node_row0[i], node_row1[i] = span[id(nd)]
+        node_leaf[i] = nd.leaf
+        idents[i] = nd.ident
+        for ch in nd.children:
+            cj = number[id(ch)]
+            node_parent[cj] = i
+            child_list.append(cj)
+        child_ptr[i + 1] = len(child_list)
+        knot_chunks[i] = pos_of[nd.knots]
+        knot_ptr[i + 1] = knot_ptr[i] + len(nd.knots)
+    knot_rows = np.concatenate(knot_chunks) if n_nodes else np.zeros(0, dtype=np.int64)
+
+    cw = np.zeros(n_levels, dtype=np.int32)
+    for m in range(n_levels):
+        ranks = [len(nd.knots) for nd in by_level[m] if not nd.leaf]
+        if ranks:
+            cw[m] = -(-max(ranks) // COL_ALIGN) * COL_ALIGN
+    preorder = np.array([number[id(nd)] for nd in flat], dtype=np.int32)
+
+    return Topology(N=N, d=d, M=M, J=J, r=r, P=P, perm=perm, src=src, in_leaf=in_leaf,
+                    n_nodes=n_nodes, n_levels=n_levels, level_ptr=level_ptr,
+                    node_level=node_level, node_row0=node_row0, node_row1=node_row1,
+                    node_leaf=node_leaf, node_parent=node_parent, child_ptr=child_ptr,
+                    child_list=np.asarray(child_list, dtype=np.int32), knot_ptr=knot_ptr,
+                    knot_rows=knot_rows, node_ident=idents, cw=cw, order_preorder=preorder)
