@@ -1,0 +1,162 @@
+/*
+ * mra_hip.h - C ABI of libmra_hip.so: the MI355X (gfx950) implementation of pyMRA's per-node
+ * prior/posterior inference hot path.
+ *
+ * The reference (marcinjurek/pyMRA) is pure Python and has no FFI boundary of its own: all of the
+ * work below happens inside its MRATree constructor.  Each entry point states which reference
+ * interface (file:line under the reference checkout) it stands in for.  The Python facade that a
+ * pyMRA user sees (pymra_amd.MRATree) binds these with ctypes; INTEGRATION.md shows the stub a
+ * pyMRA maintainer would add.
+ *
+ * Conventions: every function returns 0 on success and a negative MRA_ERR_* code on failure and
+ * never throws; mra_last_error() gives the message.  Host pointers passed in are copied before the
+ * call returns and never retained.  Results are written only into caller-allocated host buffers.
+ * A plan is bound to one GPU and one internal HIP stream; it is not thread-safe.
+ * All floating point data is IEEE binary64, all row indices refer to the caller's padded,
+ * leaf-ordered row space (see mra_topology).
+ */
+#ifndef MRA_HIP_H
+#define MRA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRA_OK                 0
+#define MRA_ERR_INVALID       -1   /* bad argument / inconsistent topology                      */
+#define MRA_ERR_HIP           -2   /* a HIP runtime call failed (no GPU, out of memory, ...)    */
+#define MRA_ERR_NOT_SPD       -3   /* a Cholesky pivot was <= 0 or NaN (reference: pdb prompt,   */
+                                   /*   pyMRA/MRANode.py:386-390)                               */
+#define MRA_ERR_STATE         -4   /* call order violated (e.g. run before set_obs)             */
+#define MRA_ERR_COMM          -5   /* RCCL failure                                              */
+
+/* stationary kernels evaluated on the device (pyMRA/MRATools.py:256-301) */
+#define MRA_KERNEL_EXP         0   /* ExpCovFun      exp(-D/l)                          :265-269 */
+#define MRA_KERNEL_MATERN32    1   /* Matern32       sig (1+sqrt3 D/l) exp(-sqrt3 D/l)  :289-293 */
+#define MRA_KERNEL_MATERN52    2   /* Matern52                                          :281-285 */
+#define MRA_KERNEL_GAUSSIAN    3   /* GaussianCovFun sig exp(-D^2/(2 l^2))              :297-301 */
+#define MRA_KERNEL_IDEN        4   /* Iden           [D == 0]                           :256-262 */
+#define MRA_KERNEL_HOST        100 /* values supplied block by block (any cov callable or a dense
+                                      matrix, pyMRA/MRANode.py:73-80, 381-384)                   */
+
+/* mra_run flags */
+#define MRA_RUN_LIKELIHOOD     1u  /* d and u                 (MRATree.getLikelihood, MRATree.py:82-84) */
+#define MRA_RUN_PREDICT        2u  /* + predictive mean / var (MRATree.predict,       MRATree.py:90-94) */
+
+typedef struct mra_plan mra_plan;
+
+/*
+ * The tree that pyMRA's Node.__init__ recursion (pyMRA/MRANode.py:23-115) would build, flattened.
+ * Rows are in depth-first leaf order and every leaf's row range is padded to a multiple of 16
+ * (phantom rows); node i owns rows [node_row0[i], node_row1[i]); nodes are numbered level by
+ * level: level m owns nodes level_ptr[m] .. level_ptr[m+1]-1; node 0 is the root.
+ * knot_rows[knot_ptr[i] .. knot_ptr[i+1]) are the padded-row positions of node i's knots
+ * (pyMRA/MRANode.py:36-45, 179-205); for a leaf they are informational only.
+ * cw[m] = knot-block width of the non-leaf nodes of level m, a multiple of 16 (0: none).
+ */
+typedef struct {
+    int64_t        P;            /* padded rows                                    */
+    int32_t        d;            /* spatial dimension, 1 or 2                      */
+    int32_t        n_levels;
+    int32_t        n_nodes;
+    const int64_t *level_ptr;    /* [n_levels + 1]                                 */
+    const int64_t *node_row0;    /* [n_nodes]                                      */
+    const int64_t *node_row1;    /* [n_nodes]                                      */
+    const uint8_t *node_leaf;    /* [n_nodes]                                      */
+    const int32_t *node_parent;  /* [n_nodes], -1 for the root                     */
+    const int32_t *child_ptr;    /* [n_nodes + 1]                                  */
+    const int32_t *child_list;   /* [child_ptr[n_nodes]]                           */
+    const int64_t *knot_ptr;     /* [n_nodes + 1]                                  */
+    const int64_t *knot_rows;    /* [knot_ptr[n_nodes]]                            */
+    const int32_t *cw;           /* [n_levels]                                     */
+} mra_topology;
+
+/* Number of usable GPUs (0 if none); never fails. */
+int mra_device_count(void);
+
+/* Replaces: the allocation side of MRATree.__init__ -> Node(...) (pyMRA/MRATree.py:69).
+ * device: HIP device ordinal.  The topology arrays are copied. */
+int mra_plan_create(mra_plan **plan, const mra_topology *topo, int device);
+int mra_plan_destroy(mra_plan *plan);
+
+/* Replaces: the `locs` argument of MRATree (pyMRA/MRATree.py:23-28).
+ * locs_perm: P x d row-major, padded leaf order (phantom rows must hold a valid location). */
+int mra_plan_set_locs(mra_plan *plan, const double *locs_perm);
+
+/* Replaces: the `obs` and `R` arguments of MRATree (pyMRA/MRATree.py:23, 61-62; NaN = missing,
+ * pyMRA/MRANode.py:415).  y_perm: P values, padded leaf order, NaN for missing and for phantom rows.
+ * R: scalar nugget variance (the reference requires a Python float, pyMRA/MRANode.py:85-88). */
+int mra_plan_set_obs(mra_plan *plan, const double *y_perm, double R);
+
+/* Replaces: the `cov` callable when it is one of pyMRA's stationary kernels
+ * (pyMRA/MRATools.py:256-301).  params = {l, sig, scale}; value = scale * k(D; l, sig). */
+int mra_plan_set_kernel(mra_plan *plan, int kind, const double *params, int n_params);
+
+/* Replaces: the `cov` callable for anything else (MRA_KERNEL_HOST): the host evaluates
+ * C(S_j, Q_j) for a non-leaf node (N_j x rank, row-major, pyMRA/MRANode.py:384) or
+ * C(S_j, O_j) for a leaf (N_j x n_obs_j; O_j = the leaf's observed rows in ascending row order)
+ * and hands it over.  diag: C(x,x) for each of the node's N_j rows (leaves only, else NULL). */
+int mra_plan_set_cov_block(mra_plan *plan, int32_t node, const double *C, int64_t n_rows,
+                           int64_t n_cols, const double *diag);
+
+/* Replaces: everything Node.__init__ computes - calculatePrior (pyMRA/MRANode.py:378-395) for
+ * every node top-down, calculatePosterior (:403-523) bottom-up.  Blocking. */
+int mra_run(mra_plan *plan, uint32_t flags);
+
+/* Replaces: MRATree.getLikelihood (pyMRA/MRATree.py:82-84): lik = *d + *u
+ * (root.d, root.u of pyMRA/MRANode.py:456-468). */
+int mra_get_likelihood(mra_plan *plan, double *d, double *u);
+
+/* Replaces: MRATree.predict (pyMRA/MRATree.py:90-94): root.mean and root.var
+ * (pyMRA/MRANode.py:510-520) in padded leaf order, P values each. */
+int mra_get_predict(mra_plan *plan, double *mean_perm, double *var_perm);
+
+/* Diagnostics for tests (the reference exposes these as attributes of Node objects):
+ * what = 0: whitened basis W (P x ldw, row-major) ; 1: per-node log-det terms (n_nodes);
+ * copies min(capacity, available) doubles into out, returns the available count in *n_avail. */
+int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int64_t *n_avail);
+
+/* Per-phase device milliseconds of the last mra_run (hipEvent deltas on the plan's stream):
+ * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written. */
+int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
+
+/* Kernel-level timing: with option MRA_OPT_KERNEL_TIMING on, every launch of mra_run is bracketed by
+ * hipEvents on the plan's stream; afterwards mra_get_kernel_stats reports, per kernel family
+ * (0 .. mra_kernel_family_count()-1), its name, the number of launches, their summed device
+ * milliseconds and the algorithmic flop count of those launches. */
+#define MRA_OPT_KERNEL_TIMING  1
+int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
+int mra_kernel_family_count(void);
+int mra_get_kernel_stats(mra_plan *plan, int which, char *name, int name_cap, int *launches, double *ms,
+                         double *flops);
+/* out[0..7] = P, ldw, Ka, n_leaves, bytes(W), bytes(leaf panels), bytes(leaf Gt), n_nodes */
+int mra_plan_info(mra_plan *plan, int64_t *out, int capacity);
+
+/* ---- multi-GPU: one process per GPU, subtrees sharded, ONE all-reduce of the shard-level fronts --
+ * The reference's only parallel mode forks one process per child subtree at `critDepth` and pickles
+ * the finished Node back (pyMRA/MRANode.py:64-65, 90-104, 114-115); here each rank owns whole
+ * subtrees and the level above them is summed with one ncclAllReduce over xGMI.               */
+int mra_comm_unique_id(char *out, int capacity);                 /* 128 bytes; rank 0 calls, then broadcast */
+int mra_comm_init(mra_plan *plan, const char *unique_id, int n_ranks, int rank);
+/* reduce_level: nodes of this level get their assembled fronts summed over ranks before they are
+ * factorised (-1: no reduction). */
+int mra_plan_set_reduce_level(mra_plan *plan, int level);
+
+/* Front exchange without RCCL (tests on one GPU, or another transport): mra_run stops before the
+ * reduce level's factorisation when MRA_RUN_SPLIT is set in flags; export/import the summed
+ * fronts, then call mra_run_resume. */
+#define MRA_RUN_SPLIT          4u
+int mra_reduce_size(mra_plan *plan, int64_t *n_doubles);
+int mra_reduce_export(mra_plan *plan, double *out);
+int mra_reduce_import(mra_plan *plan, const double *in);
+int mra_run_resume(mra_plan *plan);
+
+const char *mra_last_error(mra_plan *plan);   /* plan may be NULL: last create error */
+const char *mra_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

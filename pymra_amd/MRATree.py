@@ -1,0 +1,134 @@
+"""Drop-in ``MRATree`` with pyMRA's constructor, ``getLikelihood()`` and ``predict()``.
+
+Mirrors the public surface of pyMRA/MRATree.py:
+
+* ``MRATree(locs, r, cov, obs, R, M=-1, J=-1, critDepth=-1, verbose=True)``   MRATree.py:23
+* ``getLikelihood()`` -> 1x1 ``np.matrix`` (root.d + root.u)                  MRATree.py:82-84
+* ``predict()`` -> (N x 1 ``np.matrix`` mean, (N,) ``ndarray`` sd)            MRATree.py:90-94
+* attributes ``locs, d, r, J, M, obs_inds, root`` with ``root.d, root.u, root.mean, root.var``
+
+As in the reference all the work happens in the constructor - here it is: replay the tree on
+the host (pymra_amd.topology), hand the flat tree + locations + observations to libmra_hip.so
+through ctypes, run the HIP path once, copy the results back.  No NumPy fallback exists: without
+the library or without a GPU the constructor raises.
+
+``cov`` plug-in: the user's two-argument callable is probed once with symbolic location handles.
+If it is built from this package's kernels (``mt.ExpCovFun``, ``mt.Matern32`` ... possibly times a
+scalar) the probe yields a ``KernelSpec`` and the kernel is evaluated on the GPU.  Other callables
+and dense matrices need the host-evaluated block path (``MRA_KERNEL_HOST``).
+
+``critDepth`` is accepted for signature compatibility.  The reference's parallel mode forks one
+process per subtree at that depth (MRANode.py:90-104); the forked children inherit the same RNG
+state, so its 2-D knot draws - and therefore its results - differ from the serial mode.  This
+implementation always reproduces the serial (default) mode; GPU parallelism is over all nodes of
+a level, and multi-GPU sharding lives in pymra_amd.sharding.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from . import MRATools as mt
+from .plan import HipPlan
+from .topology import build_topology, resolve_tree_shape
+
+logger = logging.getLogger("pyMRA.MRATree")
+
+
+class RootView:
+    """The attributes of the reference's root ``Node`` that callers read."""
+
+    def __init__(self, d, u, mean, var, N, topo):
+        self.d = np.matrix([[d]])
+        self.u = np.matrix([[u]])
+        self.mean = np.matrix(mean).reshape(N, 1) if mean is not None else None
+        self.var = var
+        self.N = N
+        self.res = 0
+        self.ID = "r"
+        self.leaf = bool(topo.node_leaf[0])
+        kq = topo.knot_rows[topo.knot_ptr[0]:topo.knot_ptr[1]]
+        self.kInds = np.sort(topo.perm[kq])
+        self.children = []
+
+
+def probe_cov(cov, d):
+    """Return a KernelSpec if ``cov`` is expressible as one of the device kernels, else None."""
+    if isinstance(cov, mt.KernelSpec):
+        return cov
+    if not callable(cov):
+        return None
+    try:
+        out = cov(mt.SymbolicLocs("a", d), mt.SymbolicLocs("b", d))
+    except Exception:
+        return None
+    return out if isinstance(out, mt.KernelSpec) else None
+
+
+class MRATree(object):
+
+    def __init__(self, locs, r, cov, obs, R, M=-1, J=-1, critDepth=-1, verbose=True, device=0,
+                 want_predict=True):
+        self.locs = locs
+        self.d = np.shape(self.locs)[1]
+        N = len(locs)
+        self.r = r
+        self.M, self.J = resolve_tree_shape(N, self.d, r, M, J)
+        if critDepth < 0:
+            critDepth = self.M + 1
+        self.critDepth = critDepth
+        if not isinstance(R, float):
+            # the reference indexes a non-float R as a matrix (MRANode.py:85-88) and fails on an int
+            raise TypeError("R must be a Python float (scalar nugget variance); got %r" % type(R))
+        obs_arr = np.asarray(obs, dtype=np.float64)
+        self.obs_inds = np.where(np.logical_not(np.isnan(obs_arr)))[0]
+
+        spec = probe_cov(cov, self.d)
+        if spec is None:
+            raise NotImplementedError(
+                "cov must be built from pymra_amd.MRATools kernels (ExpCovFun, Matern32, Matern52, "
+                "GaussianCovFun, Iden; optionally times a scalar) so that it can be evaluated on the GPU; "
+                "opaque callables / dense matrices need the MRA_KERNEL_HOST block path, which this build "
+                "does not wire yet")
+        if spec.circular:
+            raise NotImplementedError("circular distances are not implemented on the device path")
+        self.kernel = spec
+
+        logger.debug('r: %d, \tJ: %d,\tM: %d' % (self.r, self.J, self.M))
+        self.topology = build_topology(np.asarray(locs, dtype=np.float64), r, self.M, self.J)
+        self.plan = HipPlan(self.topology, device=device)
+        self.plan.set_locs(locs)
+        self.plan.set_obs(obs_arr, R)
+        self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+        self.plan.run(likelihood=True, predict=want_predict)
+        d, u = self.plan.likelihood()
+        if want_predict:
+            mean, var = self.plan.predict()
+        else:
+            mean, var = None, None
+        self.root = RootView(d, u, mean, var, N, self.topology)
+
+    def getLikelihood(self):
+        return self.root.d + self.root.u
+
+    def predict(self):
+        if self.root.mean is None:
+            raise RuntimeError("constructed with want_predict=False")
+        xP = self.root.mean
+        sdP = np.sqrt(self.root.var)
+        return xP, sdP
+
+    # re-evaluate with other kernel parameters on the same tree (plan reuse for MLE loops,
+    # README.md:96-104 builds a new MRATree per objective call)
+    def reevaluate(self, cov, want_predict=False):
+        spec = probe_cov(cov, self.d)
+        if spec is None:
+            raise NotImplementedError("cov must be a device kernel")
+        self.kernel = spec
+        self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+        self.plan.run(likelihood=True, predict=want_predict)
+        d, u = self.plan.likelihood()
+        mean, var = self.plan.predict() if want_predict else (None, None)
+        self.root = RootView(d, u, mean, var, len(self.locs), self.topology)
+        return self.getLikelihood()

@@ -1,0 +1,460 @@
+// mra_kernels.h - hand-written gfx950 (CDNA4) kernels of the MRA hot path.  FP64 throughout.
+//
+// Building blocks (all batched over the nodes of one tree level; every row range, column block
+// and front size is a multiple of 16, so every MFMA tile is full):
+//
+//   k_gemm_nt      C (=|-=) A B^T on v_mfma_f64_16x16x4_f64, 32x32 output tile per wave, with three
+//                  epilogues: SET, SUB and COV (C = kernel(x_i, x_c) - A B^T : the pairwise
+//                  covariance evaluation of pyMRA/MRATools.py:229-293 fused into the conditional
+//                  covariance of pyMRA/MRANode.py:73-80, 384)
+//   k_panel_chol   left-looking blocked Cholesky of the leading ne*16 columns of a tall panel
+//                  (one workgroup per node; 16x16 diagonal blocks factorised and inverted in
+//                  registers with cross-lane shuffles, everything else on MFMA); rows below the
+//                  square part come out multiplied by L^{-T}  (np.linalg.inv / cholesky / slogdet /
+//                  scipy.linalg.inv of pyMRA/MRANode.py:387-391, 444-463)
+//   k_trsm_rows    X = R L^{-T} for tall row ranges, 16 rows per wave, X^T blocks stay in the MFMA
+//                  accumulator layout and are fed back as B operands (pyMRA/MRANode.py:384-387,
+//                  504-511)
+//   small gather / assemble / moment kernels around them.
+//
+// MFMA f64 16x16x4 operand layout (guide: cdna_hip_programming.md section 3): lane l, r = l & 15, q = l >> 4
+//   A[r][k = q]   B[k = q][r]   D[row = q + 4*reg][col = r]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MRA_YB 16
+
+__device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// "row-on-lane" tile access: element s of lane (r,q) is tile[r][q + 4 s].  The same pattern is
+// (i) the A operand of k-step s, (ii) the B operand of k-step s for a transposed product, and
+// (iii) the accumulator layout of a transposed 16x16 result - so results chain without shuffles.
+__device__ __forceinline__ d4 load_rowlane(const double* __restrict__ p, long ld, int r, int q) {
+    const double* a = p + (long)r * ld + q;
+    d4 v;
+    v[0] = a[0]; v[1] = a[4]; v[2] = a[8]; v[3] = a[12];
+    return v;
+}
+__device__ __forceinline__ void store_rowlane(double* __restrict__ p, long ld, int r, int q, d4 v) {
+    double* a = p + (long)r * ld + q;
+    a[0] = v[0]; a[4] = v[1]; a[8] = v[2]; a[12] = v[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+//  covariance kernels (pyMRA/MRATools.py:256-301); same operation order as the reference
+// ------------------------------------------------------------------------------------------------
+struct KernelParams {
+    int kind;
+    int d;
+    double l, sig, scale;
+};
+
+__device__ __forceinline__ double cov_of_dist(const KernelParams& kp, double D) {
+    double v;
+    switch (kp.kind) {
+        case 0:  v = exp(-D / kp.l); break;
+        case 1: { double t = 1.7320508075688772 * D / kp.l; v = kp.sig * ((1.0 + t) * exp(-t)); } break;
+        case 2: { double t = 2.23606797749979 * D / kp.l; double s = D / kp.l;
+                  v = kp.sig * ((1.0 + t + (5.0 / 3.0) * (s * s)) * exp(-t)); } break;
+        case 3:  v = kp.sig * exp(-(D * D) / (2.0 * (kp.l * kp.l))); break;
+        default: v = (D == 0.0) ? 1.0 : 0.0; break;
+    }
+    return kp.scale * v;
+}
+
+template <int DIM>
+__device__ __forceinline__ double pair_dist(const double* __restrict__ xa, const double* __restrict__ xb) {
+    if (DIM == 1) return fabs(xa[0] - xb[0]);
+    double dx = xa[0] - xb[0], dy = xa[1] - xb[1];
+    return sqrt(dx * dx + dy * dy);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  batched C = f(A B^T)
+// ------------------------------------------------------------------------------------------------
+struct GemmProb {
+    const double* A;        // M x K, row-major, lda
+    const double* B;        // N x K, row-major, ldb (rows optionally gathered through idxB)
+    double* C;              // M x N, row-major, ldc
+    const int* idxB;        // nullptr, or N row numbers into B (-1: zero row)
+    const double* XA;       // COV: coordinates of A's rows (row 0 of this problem), stride d
+    const double* XB;       // COV: coordinates addressed by idxB (or by column when idxB == nullptr)
+    const double* Csrc;     // HOSTCOV: host-evaluated covariance block, ldcs
+    long lda, ldb, ldc, ldcs;
+    int M, N, K;
+    int lower;              // 1: only 32x32 tiles with mt >= nt
+};
+
+enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
+
+template <int EPI, int DIM>
+__global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp) {
+    const GemmProb pb = probs[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int tn = (pb.N + 31) >> 5, tm = (pb.M + 31) >> 5;
+    const long tile = (long)blockIdx.x * 4 + wave;
+    if (tile >= (long)tm * tn) return;
+    const int mt = (int)(tile / tn), nt = (int)(tile % tn);
+    if (pb.lower && nt > mt) return;
+    const int m0 = mt << 5, n0 = nt << 5;
+    const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
+
+    const double* a0p = pb.A + (long)(m0 + r) * pb.lda + 4 * q;
+    const double* a1p = a0p + 16 * pb.lda;
+    int br0 = n0 + r, br1 = n0 + 16 + r;
+    if (pb.idxB) {
+        br0 = pb.idxB[n0 + r];
+        br1 = nv1 ? pb.idxB[n0 + 16 + r] : -1;
+    }
+    const bool bz0 = br0 < 0, bz1 = (!nv1) || br1 < 0;
+    const double* b0p = pb.B + (long)(bz0 ? 0 : br0) * pb.ldb + 4 * q;
+    const double* b1p = pb.B + (long)(bz1 ? 0 : br1) * pb.ldb + 4 * q;
+
+    d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
+    const d4 zero = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < pb.K; k0 += 16) {
+        d4 a0 = *(const d4*)(a0p + k0);
+        d4 a1 = mv1 ? *(const d4*)(a1p + k0) : zero;
+        d4 b0 = bz0 ? zero : *(const d4*)(b0p + k0);
+        d4 b1 = bz1 ? zero : *(const d4*)(b1p + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c00 = mfma16(a0[j], b0[j], c00);
+            c01 = mfma16(a0[j], b1[j], c01);
+            c10 = mfma16(a1[j], b0[j], c10);
+            c11 = mfma16(a1[j], b1[j], c11);
+        }
+    }
+    // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
+    auto emit = [&](d4 acc, int mb, int nb, int bcol) {
+        const int col = nb + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = mb + q + 4 * s;
+            double* cp = pb.C + (long)row * pb.ldc + col;
+            double v;
+            if (EPI == EPI_SET) v = acc[s];
+            else if (EPI == EPI_SUB) v = *cp - acc[s];
+            else if (EPI == EPI_COV) {
+                if (bcol < 0) v = 0.0;
+                else {
+                    double D = pair_dist<DIM>(pb.XA + (long)row * DIM, pb.XB + (long)bcol * DIM);
+                    v = cov_of_dist(kp, D) - acc[s];
+                }
+            } else {
+                v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+            }
+            *cp = v;
+        }
+    };
+    const int bc0 = pb.idxB ? br0 : n0 + r, bc1 = pb.idxB ? br1 : n0 + 16 + r;
+    emit(c00, m0, n0, bc0);
+    if (nv1) emit(c01, m0, n0 + 16, bc1);
+    if (mv1) emit(c10, m0 + 16, n0, bc0);
+    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  16x16 diagonal block: Cholesky + inverse of the factor, one row per lane (lanes 0..15)
+// ------------------------------------------------------------------------------------------------
+// a[k] = T[lane][k] (k <= lane valid).  On return a[k] = L[lane][k] (0 above the diagonal),
+// m[i] = (L^{-1})[i][lane] (column `lane` of the inverse).  Returns sum(log diag L) and sets bad
+// when a pivot is not positive.  Broadcasts go through v_readlane (scalar registers), not LDS.
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double chol16_inv(double a[16], double m[16], int lane, bool& bad) {
+    double rinv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double dj = bcast_lane(a[j], j);
+        if (!(dj > 0.0)) { bad = true; dj = 1.0; }
+        const double sq = sqrt(dj);
+        const double ri = 1.0 / sq;
+        rinv[j] = ri;
+        const double lij = (lane == j) ? sq : ((lane > j) ? a[j] * ri : 0.0);
+        a[j] = lij;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= lij * bcast_lane(lij, k);
+    }
+    // forward substitution L m = e_lane, every lane its own right-hand side
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= bcast_lane(a[k], i) * m[k];
+        m[i] = acc * rinv[i];
+    }
+    double dg = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) dg = (lane == i) ? a[i] : dg;
+    double lg = log(dg);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    return lg;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  blocked partial Cholesky of a tall panel (one workgroup per problem)
+// ------------------------------------------------------------------------------------------------
+struct PanelProb {
+    double* P;          // ht*16 rows, row-major, ld; leading ne*16 columns are eliminated
+    double* invd;       // ne blocks of 16x16: inverses of the diagonal blocks of L (row-major)
+    long ld;
+    int ht;             // row tiles
+    int ne;             // column tiles to eliminate
+    int node;           // where to put 2*sum(log diag L)
+};
+
+__global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict__ probs,
+                                                     double* __restrict__ dnode, int* __restrict__ err) {
+    const PanelProb pb = probs[blockIdx.x];
+    __shared__ double sd[16][17];
+    __shared__ double sinv[16][17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    double logacc = 0.0;
+    const d4 zero = {0, 0, 0, 0};
+    for (int jb = 0; jb < pb.ne; ++jb) {
+        // ---- phase 1: column tile jb of every row tile ib >= jb gets its left-looking update
+        for (int ib = jb + wave; ib < pb.ht; ib += 4) {
+            double* tp = pb.P + (long)ib * 16 * pb.ld + jb * 16;
+            d4 acc = load_rowlane(tp, pb.ld, r, q);
+            d4 upd = zero;
+            const double* arow = pb.P + (long)jb * 16 * pb.ld;
+            const double* brow = pb.P + (long)ib * 16 * pb.ld;
+            for (int kb = 0; kb < jb; ++kb) {
+                d4 a = load_rowlane(arow + kb * 16, pb.ld, r, q);
+                d4 b = load_rowlane(brow + kb * 16, pb.ld, r, q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) upd = mfma16(a[s], b[s], upd);
+            }
+            acc -= upd;
+            if (ib == jb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sd[r][q + 4 * s] = acc[s];
+            } else {
+                store_rowlane(tp, pb.ld, r, q, acc);
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: factorise + invert the diagonal block (wave 0)
+        if (wave == 0) {
+            double a[16], m[16];
+            const int rl = lane & 15;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (k <= rl) ? sd[rl][k] : 0.0;
+            bool bad = false;
+            double ls = chol16_inv(a, m, rl, bad);
+            logacc += ls;
+            if (lane < 16) {
+                double* dp = pb.P + (long)(jb * 16 + lane) * pb.ld + jb * 16;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dp[k] = a[k];
+                double* ip = pb.invd + (long)jb * 256;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sinv[i][lane] = m[i]; ip[i * 16 + lane] = m[i]; }
+                if (bad && lane == 0) atomicMax(err, pb.node + 1);
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: rows below: X^T = L_jj^{-1} T^T
+        {
+            d4 a;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = sinv[r][q + 4 * s];
+            for (int ib = jb + wave; ib < pb.ht; ib += 4) {
+                if (ib == jb) continue;
+                double* tp = pb.P + (long)ib * 16 * pb.ld + jb * 16;
+                d4 b = load_rowlane(tp, pb.ld, r, q);
+                d4 x = zero;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) x = mfma16(a[s], b[s], x);
+                store_rowlane(tp, pb.ld, r, q, x);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dnode[pb.node] = 2.0 * logacc;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  X = R L^{-T} on 16-row tiles (in place), optional var += rowsumsq(X)
+// ------------------------------------------------------------------------------------------------
+struct TrsmNode {
+    const double* L;      // cwt*16 square, row-major (lower part used)
+    const double* invd;   // cwt inverted diagonal blocks
+    long ldL;
+    int cwt;
+};
+
+__global__ __launch_bounds__(256) void k_trsm_rows(const TrsmNode* __restrict__ nodes,
+                                                    const int* __restrict__ tile_node,
+                                                    const long* __restrict__ tile_row0, long ntiles,
+                                                    double* __restrict__ W, long ldw, int c0,
+                                                    double* __restrict__ var) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long t = (long)blockIdx.x * 4 + wave;
+    if (t >= ntiles) return;
+    const TrsmNode nd = nodes[tile_node[t]];
+    double* wp = W + tile_row0[t] * ldw + c0;
+    const d4 zero = {0, 0, 0, 0};
+    double ssq = 0.0;
+    for (int jb = 0; jb < nd.cwt; ++jb) {
+        d4 acc = load_rowlane(wp + jb * 16, ldw, r, q);
+        d4 upd = zero;
+        for (int kb = 0; kb < jb; ++kb) {
+            d4 a = load_rowlane(nd.L + (long)jb * 16 * nd.ldL + kb * 16, nd.ldL, r, q);
+            d4 b = load_rowlane(wp + kb * 16, ldw, r, q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) upd = mfma16(a[s], b[s], upd);
+        }
+        acc -= upd;
+        d4 ia = load_rowlane(nd.invd + (long)jb * 256, 16, r, q);
+        d4 x = zero;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = mfma16(ia[s], acc[s], x);
+        store_rowlane(wp + jb * 16, ldw, r, q, x);
+        ssq += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    if (var) {
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (q == 0) var[tile_row0[t] + r] += ssq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  small kernels
+// ------------------------------------------------------------------------------------------------
+// W[:, Ka] = y (0 where missing), W[:, Ka+1 .. Ka+15] = 0
+__global__ void k_init_yblock(double* __restrict__ W, long ldw, int Ka, const double* __restrict__ y, long P) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * MRA_YB) return;
+    long p = i / MRA_YB; int c = (int)(i % MRA_YB);
+    double v = 0.0;
+    if (c == 0) { double yy = y[p]; v = isfinite(yy) ? yy : 0.0; }
+    W[p * ldw + Ka + c] = v;
+}
+
+// prior: kInv block of a node = rows of its knots out of its own conditional-covariance block
+struct KinvProb { double* Lp; const long* knots; int rank; int cw; };
+__global__ void k_gather_kinv(const KinvProb* __restrict__ probs, const double* __restrict__ W, long ldw, int c0) {
+    const KinvProb pb = probs[blockIdx.y];
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= pb.cw * pb.cw) return;
+    int a = e / pb.cw, b = e % pb.cw;
+    double v = (a == b) ? 1.0 : 0.0;
+    if (a < pb.rank && b < pb.rank) v = W[pb.knots[a] * ldw + c0 + b];
+    pb.Lp[(long)a * pb.cw + b] = v;
+}
+
+// leaf panel: [ C = V[o,o] + R I ; Ut = [W_anc[o] | y_o]^T ; V[S,o] ] -> fill the first two parts
+struct LeafProb {
+    double* Pn;           // panel base
+    const int* obs;       // nop entries: padded-row numbers of observed rows (-1 phantom)
+    long row0;            // first padded row of the leaf
+    long ld;              // = nop
+    int nrows;            // N_j
+    int nop;              // padded number of observations
+    int na;               // ancestors + y block
+    int a0;               // first ancestor column in W
+    int node;
+};
+__global__ void k_leaf_fill(const LeafProb* __restrict__ probs, const double* __restrict__ W, long ldw, double R) {
+    const LeafProb pb = probs[blockIdx.y];
+    const long total = (long)(pb.nop + pb.na) * pb.nop;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int row = (int)(e / pb.nop), k = (int)(e % pb.nop);
+        double v;
+        if (row < pb.nop) {
+            int oa = pb.obs[row], ob = pb.obs[k];
+            if (oa >= 0 && ob >= 0) {
+                v = pb.Pn[(long)(pb.nop + pb.na + (oa - pb.row0)) * pb.ld + k];
+                if (row == k) v += R;
+            } else v = (row == k) ? 1.0 : 0.0;
+        } else {
+            int t = row - pb.nop, ok = pb.obs[k];
+            v = (ok >= 0) ? W[(long)ok * ldw + pb.a0 + t] : 0.0;
+        }
+        pb.Pn[(long)row * pb.ld + k] = v;
+    }
+}
+
+// leaf moments: var = max(C(x,x) - |W_anc[x]|^2 - |Tt[x]|^2, 0); y column of W reset to 0.
+// One wave per row.
+__global__ __launch_bounds__(256) void k_leaf_moments(const LeafProb* __restrict__ probs, const int* __restrict__ row_leaf,
+                                                       double* __restrict__ W, long ldw, int Ka,
+                                                       double* __restrict__ var, double cov0,
+                                                       const double* __restrict__ diag_host, long P) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * 4 + wave;
+    if (p >= P) return;
+    const int lf = row_leaf[p];
+    if (lf < 0) return;
+    const LeafProb pb = probs[lf];
+    double s = 0.0;
+    const double* wr = W + p * ldw;
+    for (int c = pb.a0 + lane; c < Ka; c += 64) { double v = wr[c]; s += v * v; }
+    const double* tr = pb.Pn + (long)(pb.nop + pb.na + (p - pb.row0)) * pb.ld;
+    for (int k = lane; k < pb.nop; k += 64) { double v = tr[k]; s += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        double base = diag_host ? diag_host[p] : cov0;
+        double v = base - s;
+        var[p] = v > 0.0 ? v : 0.0;
+        W[p * ldw + Ka] = 0.0;
+    }
+}
+
+// non-leaf front: F = [I on the own block] + sum of the children's Schur blocks (lower triangle)
+struct AsmProb { double* F; int nf; int cw; int child0; int nchild; int add_identity; };
+struct AsmChild { const double* G; long ld; };
+__global__ void k_assemble(const AsmProb* __restrict__ probs, const AsmChild* __restrict__ kids, int add_identity) {
+    const AsmProb pb = probs[blockIdx.y];
+    const long total = (long)pb.nf * pb.nf;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        int a = (int)(e / pb.nf), b = (int)(e % pb.nf);
+        if (b > a) continue;
+        double v = (add_identity && a == b && a < pb.cw) ? 1.0 : 0.0;
+        for (int c = 0; c < pb.nchild; ++c) {
+            const AsmChild ch = kids[pb.child0 + c];
+            v += ch.G[(long)a * ch.ld + b];
+        }
+        pb.F[(long)a * pb.nf + b] = v;
+    }
+}
+__global__ void k_add_identity(const AsmProb* __restrict__ probs) {
+    const AsmProb pb = probs[blockIdx.y];
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < pb.cw) pb.F[(long)a * pb.nf + a] += 1.0;
+}
+
+// mean = -W[:, Ka]
+__global__ void k_extract_mean(const double* __restrict__ W, long ldw, int Ka, double* __restrict__ mean, long P) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) mean[p] = -W[p * ldw + Ka];
+}
+
+// d = sum of per-node log-determinants, in node order (deterministic), one workgroup
+__global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dnode, int n, double* __restrict__ out) {
+    __shared__ double part[256];
+    double s = 0.0;
+    const int chunk = (n + 255) / 256;
+    const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int i = lo; i < hi; ++i) s += dnode[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += part[i];
+        out[0] = t;
+    }
+}

@@ -1,0 +1,930 @@
+// mra_plan.hip - host side of libmra_hip.so: plan construction, batched-problem descriptors, the
+// launch sequence of one inference pass and the C ABI of include/mra_hip.h.
+//
+// One pass (mra_run) = what pyMRA's Node.__init__ recursion computes (pyMRA/MRANode.py:23-115):
+//   1. prior, top-down per level    (calculatePrior, MRANode.py:378-395, with the conditional
+//                                    covariance of :73-80)            -> whitened basis W
+//   2. leaves, observation space    (leaf branch of calculatePosterior, :411-430, :450-459)
+//   3. non-leaf fronts, bottom-up   (:432-480)
+//   4. predictive moments, bottom-up(:486-520)
+// DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
+#include "mra_kernels.h"
+#include "../../include/mra_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+#include <vector>
+
+#define MRA_VERSION_STR "mra_hip 0.1 (gfx950)"
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            char _b[512];                                                                 \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                 \
+            throw MraError(MRA_ERR_HIP, _b);                                              \
+        }                                                                                 \
+    } while (0)
+
+struct MraError {
+    int code;
+    std::string msg;
+    MraError(int c, const std::string& m) : code(c), msg(m) {}
+};
+
+enum KFam {
+    KF_PRIOR_RESID = 0, KF_PRIOR_CHOL, KF_PRIOR_TRSM, KF_LEAF_RESID, KF_LEAF_CHOL, KF_LEAF_SYRK,
+    KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
+};
+static const char* kfam_name[KF_COUNT] = {
+    "k_gemm_nt<COV> prior resid", "k_panel_chol prior", "k_trsm_rows prior", "k_gemm_nt<COV> leaf resid",
+    "k_panel_chol leaf", "k_gemm_nt<SET> leaf syrk", "k_gemm_nt<SUB> leaf update", "k_panel_chol front",
+    "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update", "small kernels"};
+
+template <class T>
+struct DevVec {
+    T* p = nullptr;
+    size_t n = 0;
+    void upload(const std::vector<T>& h) {
+        release();
+        n = h.size();
+        if (n) {
+            if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
+            if (hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
+        }
+    }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (n && hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
+            char b[160];
+            snprintf(b, sizeof b, "hipMalloc of %.3f GB failed", (double)(n * sizeof(T)) / 1e9);
+            p = nullptr;
+            throw MraError(MRA_ERR_HIP, b);
+        }
+    }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevVec() { release(); }
+};
+
+struct LevelData {
+    std::vector<int> nodes;          // non-leaf nodes of this level
+    int cw = 0, cwt = 0, c0 = 0, a0 = 0, nf = 0, na = 0;
+    long max_rows = 0;               // largest row range among the nodes
+    DevVec<double> Lp, invP, F, invF;
+    DevVec<GemmProb> gResid, gSchur, gUpdate;
+    DevVec<KinvProb> gKinv;
+    DevVec<PanelProb> gPriorChol, gFrontChol;
+    DevVec<TrsmNode> gTrsmPrior, gTrsmPost;
+    DevVec<int> tile_node;
+    DevVec<long> tile_row0;
+    long ntiles = 0;
+    DevVec<AsmProb> gAsm;
+    double fl_resid = 0, fl_pchol = 0, fl_trsm = 0, fl_fchol = 0, fl_schur = 0, fl_update = 0;
+};
+
+struct mra_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // topology (host)
+    long P = 0;
+    int d = 0, n_levels = 0, n_nodes = 0;
+    std::vector<long> level_ptr, row0, row1, knot_ptr, knot_rows;
+    std::vector<uint8_t> leaf;
+    std::vector<int> parent, child_ptr, child_list, cw, node_level;
+    // layout
+    int Ka = 0, ldw = 0;
+    std::vector<int> coff, asuf, nf, na;
+    // state
+    bool have_locs = false, have_obs = false, have_kernel = false, ran = false, split_pending = false;
+    uint32_t run_flags = 0;
+    KernelParams kp{};
+    bool host_cov = false;
+    double R = 0.0;
+    int reduce_level = -1;
+    // device data
+    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag;
+    DevVec<int> errflag, knot_idx, row_leaf;
+    DevVec<long> knots_dev;
+    std::vector<long> knot_idx_off;      // per node offset into knot_idx (padded to cw)
+    std::vector<LevelData> lev;
+    std::vector<int> node_slot;          // index of a non-leaf node inside its level's arrays
+    // leaves
+    std::vector<int> leaf_nodes;         // node numbers
+    std::vector<int> leaf_slot;          // node -> leaf index or -1
+    std::vector<int> leaf_nop;
+    std::vector<long> leaf_poff, leaf_goff, leaf_ioff;
+    DevVec<double> panel, leafInv, Gt;
+    DevVec<int> obs_idx;
+    DevVec<LeafProb> gLeaf;
+    DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
+    DevVec<PanelProb> gLeafCholFull, gLeafCholLik;
+    DevVec<AsmChild> asmKids;
+    long leaf_max_rows = 0;
+    int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
+    double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
+    // host cov staging (MRA_KERNEL_HOST)
+    std::vector<long> cov_off;           // per node offset into covsrc
+    std::vector<double> cov_host, covdiag_host;
+    // results
+    double res_d = 0, res_u = 0;
+    // timers
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double phase_ms[5] = {0, 0, 0, 0, 0};
+    bool ktiming = false;
+    struct KStat { int launches = 0; double ms = 0, flops = 0; } kstat[KF_COUNT];
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> kev;
+    // comm
+    void* rccl = nullptr;
+    void* comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+static int fail(mra_plan* p, const MraError& e) {
+    if (p) p->err = e.msg;
+    g_last_error = e.msg;
+    return e.code;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void build_static(mra_plan* pl) {
+    const int L = pl->n_levels;
+    pl->Ka = 0;
+    for (int m = 0; m < L; ++m) {
+        if (pl->cw[m] % 16) throw MraError(MRA_ERR_INVALID, "cw must be a multiple of 16");
+        pl->Ka += pl->cw[m];
+    }
+    pl->ldw = pl->Ka + MRA_YB;
+    pl->coff.assign(L, 0); pl->asuf.assign(L, 0); pl->nf.assign(L, 0); pl->na.assign(L, 0);
+    for (int m = 0; m < L; ++m) {
+        int s = 0;
+        for (int k = m + 1; k < L; ++k) s += pl->cw[k];
+        pl->coff[m] = s;
+        pl->asuf[m] = s + pl->cw[m];
+        pl->nf[m] = pl->ldw - pl->coff[m];
+        pl->na[m] = pl->ldw - pl->asuf[m];
+    }
+    pl->node_level.assign(pl->n_nodes, 0);
+    for (int m = 0; m < L; ++m)
+        for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1]; ++i) pl->node_level[i] = m;
+    for (int i = 0; i < pl->n_nodes; ++i) {
+        if ((pl->row0[i] % 16) || (pl->row1[i] % 16) || pl->row1[i] < pl->row0[i] || pl->row1[i] > pl->P)
+            throw MraError(MRA_ERR_INVALID, "node row ranges must be 16-aligned and inside [0,P)");
+        const int m = pl->node_level[i];
+        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+        if (!pl->leaf[i] && (rk > pl->cw[m] || rk <= 0)) throw MraError(MRA_ERR_INVALID, "non-leaf rank must be in 1..cw[level]");
+        if (!pl->leaf[i] && pl->child_ptr[i + 1] == pl->child_ptr[i]) throw MraError(MRA_ERR_INVALID, "non-leaf node without children");
+    }
+
+    // device arrays shared by everything
+    pl->X.alloc((size_t)pl->P * pl->d);
+    pl->y.alloc(pl->P);
+    pl->W.alloc((size_t)pl->P * pl->ldw);
+    pl->var.alloc(pl->P);
+    pl->mean.alloc(pl->P);
+    pl->dnode.alloc(pl->n_nodes);
+    pl->scal.alloc(4);
+    pl->errflag.alloc(1);
+    HIP_TRY(hipMemset(pl->W.p, 0, pl->W.n * sizeof(double)));
+    HIP_TRY(hipMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
+    HIP_TRY(hipMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
+    pl->knots_dev.upload(pl->knot_rows);
+
+    // knot index arrays for the gather side of the prior GEMM (padded to cw with -1)
+    std::vector<int> kidx;
+    pl->knot_idx_off.assign(pl->n_nodes, -1);
+    for (int i = 0; i < pl->n_nodes; ++i) {
+        if (pl->leaf[i]) continue;
+        const int m = pl->node_level[i];
+        pl->knot_idx_off[i] = (long)kidx.size();
+        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+        for (int c = 0; c < pl->cw[m]; ++c) kidx.push_back(c < rk ? (int)pl->knot_rows[pl->knot_ptr[i] + c] : -1);
+    }
+    pl->knot_idx.upload(kidx);
+
+    // per level buffers + static descriptors
+    pl->lev.clear();
+    pl->lev.resize(L);
+    pl->node_slot.assign(pl->n_nodes, -1);
+    for (int m = 0; m < L; ++m) {
+        LevelData& lv = pl->lev[m];
+        lv.cw = pl->cw[m]; lv.cwt = lv.cw / 16; lv.c0 = pl->coff[m]; lv.a0 = pl->asuf[m];
+        lv.nf = pl->nf[m]; lv.na = pl->na[m];
+        for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1]; ++i)
+            if (!pl->leaf[i]) { pl->node_slot[i] = (int)lv.nodes.size(); lv.nodes.push_back((int)i); }
+        const size_t nn = lv.nodes.size();
+        if (!nn) continue;
+        if (lv.cw == 0) throw MraError(MRA_ERR_INVALID, "level with non-leaf nodes has cw == 0");
+        lv.Lp.alloc(nn * (size_t)lv.cw * lv.cw);
+        lv.invP.alloc(nn * (size_t)lv.cwt * 256);
+        lv.F.alloc(nn * (size_t)lv.nf * lv.nf + 16);
+        lv.invF.alloc(nn * (size_t)lv.cwt * 256);
+    }
+    // leaves
+    pl->leaf_nodes.clear();
+    pl->leaf_slot.assign(pl->n_nodes, -1);
+    for (int i = 0; i < pl->n_nodes; ++i)
+        if (pl->leaf[i]) { pl->leaf_slot[i] = (int)pl->leaf_nodes.size(); pl->leaf_nodes.push_back(i); }
+    {
+        std::vector<int> rl(pl->P, -1);
+        for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+            const int i = pl->leaf_nodes[t];
+            for (long p = pl->row0[i]; p < pl->row1[i]; ++p) rl[p] = (int)t;
+        }
+        pl->row_leaf.upload(rl);
+    }
+    // Gt of the leaves
+    pl->leaf_goff.assign(pl->leaf_nodes.size() + 1, 0);
+    for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+        const int na = pl->na[pl->node_level[pl->leaf_nodes[t]]];
+        pl->leaf_goff[t + 1] = pl->leaf_goff[t] + (long)na * na;
+    }
+    pl->Gt.alloc(pl->leaf_goff.back());
+
+    // descriptors that do not depend on the observations
+    std::vector<AsmChild> kids;
+    for (int m = 0; m < L; ++m) {
+        LevelData& lv = pl->lev[m];
+        const size_t nn = lv.nodes.size();
+        if (!nn) continue;
+        std::vector<GemmProb> resid(nn), schur(nn), upd(nn);
+        std::vector<KinvProb> kinv(nn);
+        std::vector<PanelProb> pch(nn), fch(nn);
+        std::vector<TrsmNode> tpr(nn), tpo(nn);
+        std::vector<AsmProb> as(nn);
+        std::vector<int> tnode;
+        std::vector<long> trow;
+        const int Kanc = pl->Ka - lv.a0;
+        for (size_t s = 0; s < nn; ++s) {
+            const int i = lv.nodes[s];
+            const long r0 = pl->row0[i], nr = pl->row1[i] - r0;
+            lv.max_rows = std::max(lv.max_rows, nr);
+            const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+            double* Lp = lv.Lp.p + s * (size_t)lv.cw * lv.cw;
+            double* F = lv.F.p + s * (size_t)lv.nf * lv.nf;
+            GemmProb g{};
+            g.A = pl->W.p + r0 * pl->ldw + lv.a0; g.lda = pl->ldw;
+            g.B = pl->W.p + lv.a0; g.ldb = pl->ldw; g.idxB = pl->knot_idx.p + pl->knot_idx_off[i];
+            g.C = pl->W.p + r0 * pl->ldw + lv.c0; g.ldc = pl->ldw;
+            g.XA = pl->X.p + r0 * pl->d; g.XB = pl->X.p;
+            g.M = (int)nr; g.N = lv.cw; g.K = Kanc; g.lower = 0;
+            resid[s] = g;
+            lv.fl_resid += 2.0 * nr * lv.cw * Kanc;
+            kinv[s] = KinvProb{Lp, pl->knots_dev.p + pl->knot_ptr[i], (int)rk, lv.cw};
+            pch[s] = PanelProb{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt, lv.cwt, i};
+            lv.fl_pchol += (double)lv.cw * lv.cw * lv.cw / 3.0;
+            tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
+            tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
+            lv.fl_trsm += (double)nr * lv.cw * lv.cw;
+            for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
+            fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
+            lv.fl_fchol += (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw;
+            GemmProb sc{};
+            sc.A = F + (size_t)lv.cw * lv.nf; sc.lda = lv.nf; sc.B = sc.A; sc.ldb = lv.nf;
+            sc.C = F + (size_t)lv.cw * lv.nf + lv.cw; sc.ldc = lv.nf;
+            sc.M = lv.na; sc.N = lv.na; sc.K = lv.cw; sc.lower = 1;
+            schur[s] = sc;
+            lv.fl_schur += (double)lv.na * lv.na * lv.cw;
+            GemmProb u{};
+            u.A = pl->W.p + r0 * pl->ldw + lv.c0; u.lda = pl->ldw;
+            u.B = F + (size_t)lv.cw * lv.nf; u.ldb = lv.nf;
+            u.C = pl->W.p + r0 * pl->ldw + lv.a0; u.ldc = pl->ldw;
+            u.M = (int)nr; u.N = lv.na; u.K = lv.cw; u.lower = 0;
+            upd[s] = u;
+            lv.fl_update += 2.0 * nr * lv.na * lv.cw;
+            AsmProb a{};
+            a.F = F; a.nf = lv.nf; a.cw = lv.cw; a.child0 = (int)kids.size();
+            a.nchild = pl->child_ptr[i + 1] - pl->child_ptr[i]; a.add_identity = 1;
+            for (int c = pl->child_ptr[i]; c < pl->child_ptr[i + 1]; ++c) {
+                const int ch = pl->child_list[c];
+                if (pl->node_level[ch] != m + 1) throw MraError(MRA_ERR_INVALID, "child must be one level below its parent");
+                AsmChild k{};
+                if (pl->leaf[ch]) { k.G = pl->Gt.p + pl->leaf_goff[pl->leaf_slot[ch]]; k.ld = pl->na[m + 1]; }
+                else {
+                    const LevelData& cl = pl->lev[m + 1];
+                    k.G = cl.F.p + (size_t)pl->node_slot[ch] * cl.nf * cl.nf + (size_t)cl.cw * cl.nf + cl.cw;
+                    k.ld = cl.nf;
+                }
+                if (pl->na[m + 1] != lv.nf) throw MraError(MRA_ERR_INVALID, "front size mismatch");
+                kids.push_back(k);
+            }
+            as[s] = a;
+        }
+        lv.gResid.upload(resid); lv.gSchur.upload(schur); lv.gUpdate.upload(upd); lv.gKinv.upload(kinv);
+        lv.gPriorChol.upload(pch); lv.gFrontChol.upload(fch); lv.gTrsmPrior.upload(tpr); lv.gTrsmPost.upload(tpo);
+        lv.gAsm.upload(as);
+        lv.ntiles = (long)tnode.size();
+        lv.tile_node.upload(tnode); lv.tile_row0.upload(trow);
+    }
+    pl->asmKids.upload(kids);
+}
+
+// leaf descriptors: depend on which rows are observed
+static void build_leaf(mra_plan* pl, const double* y) {
+    const size_t nl = pl->leaf_nodes.size();
+    pl->leaf_nop.assign(nl, 0);
+    pl->leaf_poff.assign(nl + 1, 0);
+    pl->leaf_ioff.assign(nl + 1, 0);
+    std::vector<int> obs;
+    std::vector<long> obs_off(nl + 1, 0);
+    pl->leaf_max_rows = 0; pl->leaf_max_nop = 0; pl->leaf_max_na = 0; pl->leaf_max_ht = 0;
+    for (size_t t = 0; t < nl; ++t) {
+        const int i = pl->leaf_nodes[t];
+        const int na = pl->na[pl->node_level[i]];
+        int no = 0;
+        obs_off[t] = (long)obs.size();
+        for (long p = pl->row0[i]; p < pl->row1[i]; ++p)
+            if (std::isfinite(y[p])) { obs.push_back((int)p); ++no; }
+        const int nop = (no + 15) / 16 * 16;
+        for (int k = no; k < nop; ++k) obs.push_back(-1);
+        pl->leaf_nop[t] = nop;
+        const long nr = pl->row1[i] - pl->row0[i];
+        pl->leaf_poff[t + 1] = pl->leaf_poff[t] + (long)(nop + na + nr) * nop;
+        pl->leaf_ioff[t + 1] = pl->leaf_ioff[t] + (long)(nop / 16) * 256;
+        pl->leaf_max_rows = std::max(pl->leaf_max_rows, nr);
+        pl->leaf_max_nop = std::max(pl->leaf_max_nop, nop);
+        pl->leaf_max_na = std::max(pl->leaf_max_na, na);
+        pl->leaf_max_ht = std::max(pl->leaf_max_ht, (int)((nop + na + nr) / 16));
+    }
+    obs_off[nl] = (long)obs.size();
+    pl->obs_idx.upload(obs);
+    pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
+    pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
+    std::vector<LeafProb> lp(nl);
+    std::vector<GemmProb> gr(nl), gs(nl), gu(nl);
+    std::vector<PanelProb> pf(nl), pk(nl);
+    pl->fl_leaf_resid = pl->fl_leaf_chol = pl->fl_leaf_chol_lik = pl->fl_leaf_syrk = pl->fl_leaf_update = 0;
+    for (size_t t = 0; t < nl; ++t) {
+        const int i = pl->leaf_nodes[t];
+        const int m = pl->node_level[i];
+        const int na = pl->na[m], a0 = pl->asuf[m], nop = pl->leaf_nop[t];
+        const long r0 = pl->row0[i], nr = pl->row1[i] - r0;
+        const int Kanc = pl->Ka - a0;
+        double* Pn = pl->panel.p + pl->leaf_poff[t];
+        LeafProb q{};
+        q.Pn = Pn; q.obs = pl->obs_idx.p + obs_off[t]; q.row0 = r0; q.ld = nop; q.nrows = (int)nr;
+        q.nop = nop; q.na = na; q.a0 = a0; q.node = i;
+        lp[t] = q;
+        GemmProb g{};
+        g.A = pl->W.p + r0 * pl->ldw + a0; g.lda = pl->ldw;
+        g.B = pl->W.p + a0; g.ldb = pl->ldw; g.idxB = q.obs;
+        g.C = Pn + (size_t)(nop + na) * nop; g.ldc = nop;
+        g.XA = pl->X.p + r0 * pl->d; g.XB = pl->X.p;
+        g.M = (int)nr; g.N = nop; g.K = Kanc; g.lower = 0;
+        gr[t] = g;
+        pl->fl_leaf_resid += 2.0 * nr * nop * Kanc;
+        double* inv = pl->leafInv.p + pl->leaf_ioff[t];
+        pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
+        pk[t] = PanelProb{Pn, inv, nop, (nop + na) / 16, nop / 16, i};
+        pl->fl_leaf_chol += (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop;
+        pl->fl_leaf_chol_lik += (double)nop * nop * nop / 3.0 + (double)na * nop * nop;
+        GemmProb s{};
+        s.A = Pn + (size_t)nop * nop; s.lda = nop; s.B = s.A; s.ldb = nop;
+        s.C = pl->Gt.p + pl->leaf_goff[t]; s.ldc = na; s.M = na; s.N = na; s.K = nop; s.lower = 1;
+        gs[t] = s;
+        pl->fl_leaf_syrk += (double)na * na * nop;
+        GemmProb u{};
+        u.A = Pn + (size_t)(nop + na) * nop; u.lda = nop; u.B = Pn + (size_t)nop * nop; u.ldb = nop;
+        u.C = pl->W.p + r0 * pl->ldw + a0; u.ldc = pl->ldw; u.M = (int)nr; u.N = na; u.K = nop; u.lower = 0;
+        gu[t] = u;
+        pl->fl_leaf_update += 2.0 * nr * na * nop;
+    }
+    pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
+    pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  launch helpers
+// ------------------------------------------------------------------------------------------------
+struct KTimer {
+    mra_plan* pl; int fam; hipEvent_t a = nullptr, b = nullptr;
+    KTimer(mra_plan* p, int f, double flops) : pl(p), fam(f) {
+        pl->kstat[fam].launches += 1;
+        pl->kstat[fam].flops += flops;
+        if (pl->ktiming) {
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a, pl->stream);
+        }
+    }
+    ~KTimer() {
+        if (pl->ktiming) {
+            hipEventRecord(b, pl->stream);
+            pl->kev.push_back({fam, {a, b}});
+        }
+    }
+};
+
+static inline unsigned gemm_grid_x(long M, long N) {
+    const long tm = (M + 31) / 32, tn = (N + 31) / 32;
+    return (unsigned)((tm * tn + 3) / 4);
+}
+
+template <int EPI>
+static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN) {
+    if (!nprob || maxM <= 0 || maxN <= 0) return;
+    const unsigned gx = gemm_grid_x(maxM, maxN);
+    for (size_t off = 0; off < nprob; off += 65535) {
+        const unsigned gy = (unsigned)std::min<size_t>(65535, nprob - off);
+        dim3 grid(gx, gy);
+        if (pl->d == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 1>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+        else hipLaunchKernelGGL((k_gemm_nt<EPI, 2>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+    }
+}
+
+static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob) {
+    if (!nprob) return;
+    hipLaunchKernelGGL(k_panel_chol, dim3((unsigned)nprob), dim3(256), 0, pl->stream, probs, pl->dnode.p, pl->errflag.p);
+}
+
+static void phase_mark(mra_plan* pl, int k) { hipEventRecord(pl->ev[k], pl->stream); }
+
+static void run_front_level(mra_plan* pl, int m) {
+    LevelData& lv = pl->lev[m];
+    const size_t nn = lv.nodes.size();
+    if (!nn) return;
+    { KTimer kt(pl, KF_FRONT_CHOL, lv.fl_fchol); launch_panel(pl, lv.gFrontChol.p, nn); }
+    { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na); }
+}
+
+static void run_assemble_level(mra_plan* pl, int m, bool with_identity) {
+    LevelData& lv = pl->lev[m];
+    const size_t nn = lv.nodes.size();
+    if (!nn) return;
+    KTimer kt(pl, KF_MISC, 0);
+    const long total = (long)lv.nf * lv.nf;
+    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nn);
+    hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, pl->stream, lv.gAsm.p, pl->asmKids.p, with_identity ? 1 : 0);
+}
+
+static void run_add_identity(mra_plan* pl, int m) {
+    LevelData& lv = pl->lev[m];
+    const size_t nn = lv.nodes.size();
+    if (!nn) return;
+    KTimer kt(pl, KF_MISC, 0);
+    hipLaunchKernelGGL(k_add_identity, dim3((unsigned)((lv.cw + 63) / 64), (unsigned)nn), dim3(64), 0, pl->stream, lv.gAsm.p);
+}
+
+static void finish_run(mra_plan* pl);
+
+static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
+    for (int m = m_from; m >= 0; --m) {
+        const bool is_red = (m == pl->reduce_level);
+        if (!(resume && m == m_from)) {
+            run_assemble_level(pl, m, !is_red);
+            if (is_red) {
+                // the reduce level's fronts are summed over ranks WITHOUT their identity blocks; the
+                // 16-double tail of the buffer carries the rank-local log-det sum of everything below
+                LevelData& lv = pl->lev[m];
+                const int lo = (int)pl->level_ptr[m + 1];
+                {
+                    KTimer kt(pl, KF_MISC, 0);
+                    hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p + lo, pl->n_nodes - lo,
+                                       lv.F.p + (lv.F.n - 16));
+                }
+                if (pl->run_flags & MRA_RUN_SPLIT) { pl->split_pending = true; return; }
+                if (pl->comm) {
+                    typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+                    allreduce_t fn = (allreduce_t)dlsym(pl->rccl, "ncclAllReduce");
+                    if (!fn) throw MraError(MRA_ERR_COMM, "ncclAllReduce not found");
+                    const int rc = fn(lv.F.p, lv.F.p, lv.F.n, /*ncclDouble*/ 8, /*ncclSum*/ 0, pl->comm, pl->stream);
+                    if (rc != 0) throw MraError(MRA_ERR_COMM, "ncclAllReduce failed");
+                }
+            }
+        }
+        if (is_red) run_add_identity(pl, m);
+        run_front_level(pl, m);
+    }
+    phase_mark(pl, 3);
+    if (pl->run_flags & MRA_RUN_PREDICT) {
+        for (int m = pl->n_levels - 1; m >= 0; --m) {
+            LevelData& lv = pl->lev[m];
+            const size_t nn = lv.nodes.size();
+            if (!nn) continue;
+            {
+                KTimer kt(pl, KF_PRED_TRSM, lv.fl_trsm);
+                hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
+                                   lv.gTrsmPost.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw,
+                                   lv.c0, pl->var.p);
+            }
+            { KTimer kt(pl, KF_PRED_UPDATE, lv.fl_update); launch_gemm<EPI_SUB>(pl, lv.gUpdate.p, nn, lv.max_rows, lv.na); }
+        }
+    }
+    phase_mark(pl, 4);
+    finish_run(pl);
+}
+
+static void finish_run(mra_plan* pl) {
+    {
+        KTimer kt(pl, KF_MISC, 0);
+        const int nsum = pl->reduce_level >= 0 ? (int)pl->level_ptr[pl->reduce_level + 1] : pl->n_nodes;
+        hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->scal.p);
+        if (pl->run_flags & MRA_RUN_PREDICT)
+            hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
+                               pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
+    }
+    phase_mark(pl, 5);
+    HIP_TRY(hipStreamSynchronize(pl->stream));
+    HIP_TRY(hipGetLastError());
+    int errv = 0;
+    HIP_TRY(hipMemcpy(&errv, pl->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
+    double dsum = 0, u = 0;
+    HIP_TRY(hipMemcpy(&dsum, pl->scal.p, sizeof(double), hipMemcpyDeviceToHost));
+    const double* up;
+    if (pl->leaf[0]) up = pl->Gt.p + pl->leaf_goff[pl->leaf_slot[0]] + (size_t)(pl->na[0] - MRA_YB) * pl->na[0] + (pl->na[0] - MRA_YB);
+    else {
+        const LevelData& l0 = pl->lev[0];
+        up = l0.F.p + (size_t)(l0.nf - MRA_YB) * l0.nf + (l0.nf - MRA_YB);
+    }
+    HIP_TRY(hipMemcpy(&u, up, sizeof(double), hipMemcpyDeviceToHost));
+    if (pl->reduce_level >= 0) {
+        double below = 0;
+        const LevelData& lr = pl->lev[pl->reduce_level];
+        if (lr.F.n) HIP_TRY(hipMemcpy(&below, lr.F.p + (lr.F.n - 16), sizeof(double), hipMemcpyDeviceToHost));
+        dsum += below;
+    }
+    pl->res_d = dsum; pl->res_u = u;
+    float ms;
+    for (int k = 0; k < 4; ++k) {
+        static const int a[4] = {0, 1, 2, 3}, b[4] = {1, 2, 3, 4};
+        hipEventElapsedTime(&ms, pl->ev[a[k]], pl->ev[b[k]]);
+        pl->phase_ms[k] = ms;
+    }
+    hipEventElapsedTime(&ms, pl->ev[0], pl->ev[5]);
+    pl->phase_ms[4] = ms;
+    for (auto& e : pl->kev) {
+        hipEventElapsedTime(&ms, e.second.first, e.second.second);
+        pl->kstat[e.first].ms += ms;
+        hipEventDestroy(e.second.first); hipEventDestroy(e.second.second);
+    }
+    pl->kev.clear();
+    pl->ran = true;
+    pl->split_pending = false;
+    if (errv) {
+        char b[160];
+        snprintf(b, sizeof b, "matrix not positive definite in node %d (Cholesky pivot <= 0 or NaN)", errv - 1);
+        throw MraError(MRA_ERR_NOT_SPD, b);
+    }
+}
+
+static void run_all(mra_plan* pl, uint32_t flags) {
+    if (!(pl->have_locs && pl->have_obs && pl->have_kernel))
+        throw MraError(MRA_ERR_STATE, "mra_run needs set_locs, set_obs and set_kernel first");
+    HIP_TRY(hipSetDevice(pl->device));
+    pl->run_flags = flags;
+    for (int k = 0; k < KF_COUNT; ++k) pl->kstat[k] = mra_plan::KStat();
+    HIP_TRY(hipMemsetAsync(pl->errflag.p, 0, sizeof(int), pl->stream));
+    const bool pred = flags & MRA_RUN_PREDICT;
+    phase_mark(pl, 0);
+    {
+        KTimer kt(pl, KF_MISC, 0);
+        const long n = pl->P * MRA_YB;
+        hipLaunchKernelGGL(k_init_yblock, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pl->stream, pl->W.p,
+                           (long)pl->ldw, pl->Ka, pl->y.p, pl->P);
+    }
+    // ---- 1. prior, top-down
+    for (int m = 0; m < pl->n_levels; ++m) {
+        LevelData& lv = pl->lev[m];
+        const size_t nn = lv.nodes.size();
+        if (!nn) continue;
+        {
+            KTimer kt(pl, KF_PRIOR_RESID, lv.fl_resid);
+            if (pl->host_cov) launch_gemm<EPI_HOSTCOV>(pl, lv.gResid.p, nn, lv.max_rows, lv.cw);
+            else launch_gemm<EPI_COV>(pl, lv.gResid.p, nn, lv.max_rows, lv.cw);
+        }
+        {
+            KTimer kt(pl, KF_MISC, 0);
+            dim3 grid((unsigned)((lv.cw * lv.cw + 255) / 256), (unsigned)nn);
+            hipLaunchKernelGGL(k_gather_kinv, grid, dim3(256), 0, pl->stream, lv.gKinv.p, pl->W.p, (long)pl->ldw, lv.c0);
+        }
+        { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
+        {
+            KTimer kt(pl, KF_PRIOR_TRSM, lv.fl_trsm);
+            hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
+                               lv.gTrsmPrior.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw, lv.c0,
+                               (double*)nullptr);
+        }
+    }
+    phase_mark(pl, 1);
+    // ---- 2. leaves
+    const size_t nl = pl->leaf_nodes.size();
+    if (nl) {
+        {
+            KTimer kt(pl, KF_LEAF_RESID, pl->fl_leaf_resid);
+            if (pl->host_cov) launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
+            else launch_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
+        }
+        if (pl->leaf_max_nop > 0) {
+            KTimer kt(pl, KF_MISC, 0);
+            const long total = (long)(pl->leaf_max_nop + pl->leaf_max_na) * pl->leaf_max_nop;
+            dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nl);
+            hipLaunchKernelGGL(k_leaf_fill, grid, dim3(256), 0, pl->stream, pl->gLeaf.p, pl->W.p, (long)pl->ldw, pl->R);
+        }
+        {
+            KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
+            launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
+        }
+        { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na); }
+        if (pred) {
+            {
+                KTimer kt(pl, KF_MISC, 0);
+                double cov0 = 0.0;
+                if (!pl->host_cov) {
+                    // stationary kernel: C(x,x) = scale * k(0)
+                    KernelParams kp = pl->kp;
+                    switch (kp.kind) {
+                        case 0: cov0 = kp.scale * 1.0; break;
+                        case 1: case 2: case 3: cov0 = kp.scale * kp.sig; break;
+                        default: cov0 = kp.scale; break;
+                    }
+                }
+                hipLaunchKernelGGL(k_leaf_moments, dim3((unsigned)((pl->P + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeaf.p,
+                                   pl->row_leaf.p, pl->W.p, (long)pl->ldw, pl->Ka, pl->var.p, cov0,
+                                   pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
+            }
+            { KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update); launch_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl, pl->leaf_max_rows, pl->leaf_max_na); }
+        }
+    }
+    phase_mark(pl, 2);
+    // ---- 3./4. fronts bottom-up, then predictive moments
+    run_fronts_and_predict(pl, pl->n_levels - 1, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* mra_version(void) { return MRA_VERSION_STR; }
+
+const char* mra_last_error(mra_plan* plan) { return plan ? plan->err.c_str() : g_last_error.c_str(); }
+
+int mra_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
+    if (!out || !t) return MRA_ERR_INVALID;
+    *out = nullptr;
+    mra_plan* pl = nullptr;
+    try {
+        if (t->P <= 0 || (t->d != 1 && t->d != 2) || t->n_levels <= 0 || t->n_nodes <= 0)
+            throw MraError(MRA_ERR_INVALID, "bad topology header");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw MraError(MRA_ERR_HIP, "no HIP device available: libmra_hip needs an AMD GPU (gfx950); there is no CPU fallback");
+        if (device < 0 || device >= ndev) throw MraError(MRA_ERR_INVALID, "device ordinal out of range");
+        HIP_TRY(hipSetDevice(device));
+        pl = new mra_plan();
+        pl->device = device;
+        pl->P = t->P; pl->d = t->d; pl->n_levels = t->n_levels; pl->n_nodes = t->n_nodes;
+        pl->level_ptr.assign(t->level_ptr, t->level_ptr + t->n_levels + 1);
+        pl->row0.assign(t->node_row0, t->node_row0 + t->n_nodes);
+        pl->row1.assign(t->node_row1, t->node_row1 + t->n_nodes);
+        pl->leaf.assign(t->node_leaf, t->node_leaf + t->n_nodes);
+        pl->parent.assign(t->node_parent, t->node_parent + t->n_nodes);
+        pl->child_ptr.assign(t->child_ptr, t->child_ptr + t->n_nodes + 1);
+        pl->child_list.assign(t->child_list, t->child_list + pl->child_ptr.back());
+        pl->knot_ptr.assign(t->knot_ptr, t->knot_ptr + t->n_nodes + 1);
+        pl->knot_rows.assign(t->knot_rows, t->knot_rows + pl->knot_ptr.back());
+        pl->cw.assign(t->cw, t->cw + t->n_levels);
+        if (pl->level_ptr[0] != 0 || pl->level_ptr.back() != t->n_nodes) throw MraError(MRA_ERR_INVALID, "level_ptr inconsistent");
+        HIP_TRY(hipStreamCreate(&pl->stream));
+        for (int k = 0; k < 6; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
+        build_static(pl);
+        *out = pl;
+        return MRA_OK;
+    } catch (const MraError& e) {
+        int rc = fail(nullptr, e);
+        delete pl;
+        return rc;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        delete pl;
+        return MRA_ERR_INVALID;
+    }
+}
+
+int mra_plan_destroy(mra_plan* pl) {
+    if (!pl) return MRA_OK;
+    hipSetDevice(pl->device);
+    if (pl->comm && pl->rccl) {
+        typedef int (*destroy_t)(void*);
+        destroy_t fn = (destroy_t)dlsym(pl->rccl, "ncclCommDestroy");
+        if (fn) fn(pl->comm);
+    }
+    for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
+    if (pl->stream) hipStreamDestroy(pl->stream);
+    delete pl;
+    return MRA_OK;
+}
+
+int mra_plan_set_locs(mra_plan* pl, const double* locs) {
+    if (!pl || !locs) return MRA_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(hipMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
+        pl->have_locs = true;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_plan_set_obs(mra_plan* pl, const double* y, double R) {
+    if (!pl || !y) return MRA_ERR_INVALID;
+    try {
+        if (!(R > 0.0)) throw MraError(MRA_ERR_INVALID, "R must be a positive scalar");
+        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(hipMemcpy(pl->y.p, y, (size_t)pl->P * sizeof(double), hipMemcpyHostToDevice));
+        pl->R = R;
+        build_leaf(pl, y);
+        pl->have_obs = true;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
+    if (!pl) return MRA_ERR_INVALID;
+    try {
+        if (kind == MRA_KERNEL_HOST)
+            throw MraError(MRA_ERR_STATE, "host-evaluated covariance blocks are not wired in this build");
+        if (kind < 0 || kind > MRA_KERNEL_IDEN || !params || n < 3) throw MraError(MRA_ERR_INVALID, "unknown kernel kind or too few parameters (need l, sig, scale)");
+        if (!(params[0] > 0.0)) throw MraError(MRA_ERR_INVALID, "length scale must be positive");
+        pl->kp.kind = kind; pl->kp.d = pl->d; pl->kp.l = params[0]; pl->kp.sig = params[1]; pl->kp.scale = params[2];
+        pl->host_cov = false;
+        pl->have_kernel = true;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_plan_set_cov_block(mra_plan* pl, int32_t node, const double* C, int64_t n_rows, int64_t n_cols, const double* diag) {
+    (void)node; (void)C; (void)n_rows; (void)n_cols; (void)diag;
+    if (!pl) return MRA_ERR_INVALID;
+    return fail(pl, MraError(MRA_ERR_STATE, "host-evaluated covariance blocks are not wired in this build"));
+}
+
+int mra_run(mra_plan* pl, uint32_t flags) {
+    if (!pl) return MRA_ERR_INVALID;
+    try {
+        if (!(flags & (MRA_RUN_LIKELIHOOD | MRA_RUN_PREDICT))) throw MraError(MRA_ERR_INVALID, "flags must request likelihood and/or predict");
+        run_all(pl, flags);
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_run_resume(mra_plan* pl) {
+    if (!pl) return MRA_ERR_INVALID;
+    try {
+        if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
+        HIP_TRY(hipSetDevice(pl->device));
+        run_fronts_and_predict(pl, pl->reduce_level, true);
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_get_likelihood(mra_plan* pl, double* d, double* u) {
+    if (!pl || !d || !u) return MRA_ERR_INVALID;
+    if (!pl->ran) return fail(pl, MraError(MRA_ERR_STATE, "mra_run has not completed"));
+    *d = pl->res_d; *u = pl->res_u;
+    return MRA_OK;
+}
+
+int mra_get_predict(mra_plan* pl, double* mean, double* var) {
+    if (!pl || !mean || !var) return MRA_ERR_INVALID;
+    try {
+        if (!pl->ran || !(pl->run_flags & MRA_RUN_PREDICT)) throw MraError(MRA_ERR_STATE, "mra_run with MRA_RUN_PREDICT has not completed");
+        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(hipMemcpy(mean, pl->mean.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(var, pl->var.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_avail) {
+    if (!pl || !n_avail) return MRA_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(pl->device));
+        const double* src = nullptr; int64_t n = 0;
+        if (what == 0) { src = pl->W.p; n = (int64_t)pl->W.n; }
+        else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
+        else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
+        *n_avail = n;
+        if (out && cap > 0) HIP_TRY(hipMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_get_timers(mra_plan* pl, double* out, int cap) {
+    if (!pl || !out) return 0;
+    int n = std::min(cap, 5);
+    for (int k = 0; k < n; ++k) out[k] = pl->phase_ms[k];
+    return n;
+}
+
+int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
+    if (!pl) return MRA_ERR_INVALID;
+    if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
+    return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
+}
+
+int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int* launches, double* ms, double* flops) {
+    if (!pl || which < 0 || which >= KF_COUNT) return MRA_ERR_INVALID;
+    if (name && name_cap > 0) { strncpy(name, kfam_name[which], name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = pl->kstat[which].launches;
+    if (ms) *ms = pl->kstat[which].ms;
+    if (flops) *flops = pl->kstat[which].flops;
+    return MRA_OK;
+}
+
+int mra_kernel_family_count(void) { return KF_COUNT; }
+
+int mra_plan_info(mra_plan* pl, int64_t* out, int cap) {
+    if (!pl || !out) return 0;
+    int64_t v[8] = {pl->P, pl->ldw, pl->Ka, (int64_t)pl->leaf_nodes.size(), (int64_t)pl->W.n * 8,
+                    (int64_t)pl->panel.n * 8, (int64_t)pl->Gt.n * 8, pl->n_nodes};
+    int n = std::min(cap, 8);
+    for (int k = 0; k < n; ++k) out[k] = v[k];
+    return n;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------
+int mra_plan_set_reduce_level(mra_plan* pl, int level) {
+    if (!pl) return MRA_ERR_INVALID;
+    if (level >= pl->n_levels) return fail(pl, MraError(MRA_ERR_INVALID, "reduce level out of range"));
+    pl->reduce_level = level;
+    return MRA_OK;
+}
+
+int mra_reduce_size(mra_plan* pl, int64_t* n) {
+    if (!pl || !n) return MRA_ERR_INVALID;
+    if (pl->reduce_level < 0) return fail(pl, MraError(MRA_ERR_STATE, "no reduce level set"));
+    *n = (int64_t)pl->lev[pl->reduce_level].F.n;
+    return MRA_OK;
+}
+
+int mra_reduce_export(mra_plan* pl, double* out) {
+    if (!pl || !out) return MRA_ERR_INVALID;
+    try {
+        if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
+        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(hipStreamSynchronize(pl->stream));
+        LevelData& lv = pl->lev[pl->reduce_level];
+        HIP_TRY(hipMemcpy(out, lv.F.p, lv.F.n * sizeof(double), hipMemcpyDeviceToHost));
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_reduce_import(mra_plan* pl, const double* in) {
+    if (!pl || !in) return MRA_ERR_INVALID;
+    try {
+        if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
+        HIP_TRY(hipSetDevice(pl->device));
+        LevelData& lv = pl->lev[pl->reduce_level];
+        HIP_TRY(hipMemcpy(lv.F.p, in, lv.F.n * sizeof(double), hipMemcpyHostToDevice));
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_comm_unique_id(char* out, int cap) {
+    if (!out || cap < 128) return MRA_ERR_INVALID;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_last_error = "cannot load librccl.so"; return MRA_ERR_COMM; }
+    typedef int (*uid_t_)(void*);
+    uid_t_ fn = (uid_t_)dlsym(h, "ncclGetUniqueId");
+    if (!fn || fn(out) != 0) { g_last_error = "ncclGetUniqueId failed"; return MRA_ERR_COMM; }
+    return MRA_OK;
+}
+
+int mra_comm_init(mra_plan* pl, const char* uid, int n_ranks, int rank) {
+    if (!pl || !uid) return MRA_ERR_INVALID;
+    try {
+        HIP_TRY(hipSetDevice(pl->device));
+        pl->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!pl->rccl) pl->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!pl->rccl) throw MraError(MRA_ERR_COMM, "cannot load librccl.so");
+        struct Uid { char b[128]; } id;
+        memcpy(id.b, uid, 128);
+        typedef int (*init_t)(void**, int, Uid, int);
+        init_t fn = (init_t)dlsym(pl->rccl, "ncclCommInitRank");
+        if (!fn) throw MraError(MRA_ERR_COMM, "ncclCommInitRank not found");
+        if (fn(&pl->comm, n_ranks, id, rank) != 0) throw MraError(MRA_ERR_COMM, "ncclCommInitRank failed");
+        pl->n_ranks = n_ranks; pl->rank = rank;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+"""ctypes binding of libmra_hip.so (include/mra_hip.h) - the only way the Python host reaches the GPU.
+
+There is deliberately no CPU fallback: if the shared library is missing, or no AMD GPU is
+visible when a plan is created, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmra_hip.so")
+
+MRA_RUN_LIKELIHOOD = 1
+MRA_RUN_PREDICT = 2
+MRA_RUN_SPLIT = 4
+MRA_KERNEL_HOST = 100
+MRA_OPT_KERNEL_TIMING = 1
+
+ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4: "MRA_ERR_STATE",
+             -5: "MRA_ERR_COMM"}
+
+# every symbol include/mra_hip.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "mra_device_count", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
+    "mra_plan_set_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
+    "mra_get_buffer", "mra_get_timers", "mra_plan_set_option", "mra_kernel_family_count",
+    "mra_get_kernel_stats", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
+    "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
+    "mra_run_resume", "mra_last_error", "mra_version",
+]
+
+
+class MraTopologyStruct(C.Structure):
+    _fields_ = [("P", C.c_int64), ("d", C.c_int32), ("n_levels", C.c_int32), ("n_nodes", C.c_int32),
+                ("level_ptr", C.c_void_p), ("node_row0", C.c_void_p), ("node_row1", C.c_void_p),
+                ("node_leaf", C.c_void_p), ("node_parent", C.c_void_p), ("child_ptr", C.c_void_p),
+                ("child_list", C.c_void_p), ("knot_ptr", C.c_void_p), ("knot_rows", C.c_void_p),
+                ("cw", C.c_void_p)]
+
+
+class MraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libmra_hip.so (built by __graft_entry__.build()).  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("pymra_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
+    sig = {
+        "mra_device_count": (C.c_int, []),
+        "mra_plan_create": (C.c_int, [C.POINTER(vp), C.POINTER(MraTopologyStruct), C.c_int]),
+        "mra_plan_destroy": (C.c_int, [vp]),
+        "mra_plan_set_locs": (C.c_int, [vp, vp]),
+        "mra_plan_set_obs": (C.c_int, [vp, vp, dbl]),
+        "mra_plan_set_kernel": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+        "mra_plan_set_cov_block": (C.c_int, [vp, i32, vp, i64, i64, vp]),
+        "mra_run": (C.c_int, [vp, u32]),
+        "mra_run_resume": (C.c_int, [vp]),
+        "mra_get_likelihood": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl)]),
+        "mra_get_predict": (C.c_int, [vp, vp, vp]),
+        "mra_get_buffer": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(i64)]),
+        "mra_get_timers": (C.c_int, [vp, vp, C.c_int]),
+        "mra_plan_set_option": (C.c_int, [vp, C.c_int, i64]),
+        "mra_kernel_family_count": (C.c_int, []),
+        "mra_get_kernel_stats": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl), C.POINTER(dbl)]),
+        "mra_plan_info": (C.c_int, [vp, vp, C.c_int]),
+        "mra_comm_unique_id": (C.c_int, [C.c_char_p, C.c_int]),
+        "mra_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
+        "mra_plan_set_reduce_level": (C.c_int, [vp, C.c_int]),
+        "mra_reduce_size": (C.c_int, [vp, C.POINTER(i64)]),
+        "mra_reduce_export": (C.c_int, [vp, vp]),
+        "mra_reduce_import": (C.c_int, [vp, vp]),
+        "mra_last_error": (C.c_char_p, [vp]),
+        "mra_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipPlan:
+    """One MRA tree on one GPU.  Thin, stateful wrapper of the C ABI."""
+
+    def __init__(self, topo, device: int = 0):
+        self.lib = load_library()
+        self.topo = topo
+        self._h = C.c_void_p()
+        # keep the arrays alive (and of the exact dtypes the header declares) during the call
+        arrs = dict(
+            level_ptr=np.ascontiguousarray(topo.level_ptr, dtype=np.int64),
+            node_row0=np.ascontiguousarray(topo.node_row0, dtype=np.int64),
+            node_row1=np.ascontiguousarray(topo.node_row1, dtype=np.int64),
+            node_leaf=np.ascontiguousarray(topo.node_leaf, dtype=np.uint8),
+            node_parent=np.ascontiguousarray(topo.node_parent, dtype=np.int32),
+            child_ptr=np.ascontiguousarray(topo.child_ptr, dtype=np.int32),
+            child_list=np.ascontiguousarray(topo.child_list, dtype=np.int32),
+            knot_ptr=np.ascontiguousarray(topo.knot_ptr, dtype=np.int64),
+            knot_rows=np.ascontiguousarray(topo.knot_rows, dtype=np.int64),
+            cw=np.ascontiguousarray(topo.cw, dtype=np.int32),
+        )
+        st = MraTopologyStruct(P=int(topo.P), d=int(topo.d), n_levels=int(topo.n_levels), n_nodes=int(topo.n_nodes),
+                               **{k: _ptr(v) for k, v in arrs.items()})
+        rc = self.lib.mra_plan_create(C.byref(self._h), C.byref(st), int(device))
+        if rc != 0:
+            msg = self.lib.mra_last_error(None)
+            self._h = C.c_void_p()
+            raise MraError(rc, msg.decode() if msg else "")
+        self.P = int(topo.P)
+        self.d = int(topo.d)
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.mra_last_error(self._h)
+            raise MraError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.mra_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs --------------------------------------------------------------------------------
+    def set_locs(self, locs):
+        """locs: the caller's N x d array; permuted/padded here."""
+        X = np.asarray(locs, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1)
+        Xp = np.ascontiguousarray(X[self.topo.src])
+        self._check(self.lib.mra_plan_set_locs(self._h, _ptr(Xp)))
+
+    def set_obs(self, obs, R):
+        y = np.asarray(obs, dtype=np.float64).reshape(-1)
+        yp = y[self.topo.src].copy()
+        yp[self.topo.perm < 0] = np.nan
+        yp = np.ascontiguousarray(yp)
+        self._check(self.lib.mra_plan_set_obs(self._h, _ptr(yp), float(R)))
+
+    def set_kernel(self, kind, l, sig=1.0, scale=1.0):
+        par = np.array([l, sig, scale], dtype=np.float64)
+        self._check(self.lib.mra_plan_set_kernel(self._h, int(kind), _ptr(par), 3))
+
+    def set_option(self, option, value):
+        self._check(self.lib.mra_plan_set_option(self._h, int(option), int(value)))
+
+    # -- run / results -----------------------------------------------------------------------------
+    def run(self, likelihood=True, predict=True, split=False):
+        flags = (MRA_RUN_LIKELIHOOD if likelihood else 0) | (MRA_RUN_PREDICT if predict else 0) | (MRA_RUN_SPLIT if split else 0)
+        self._check(self.lib.mra_run(self._h, flags))
+
+    def resume(self):
+        self._check(self.lib.mra_run_resume(self._h))
+
+    def likelihood(self):
+        d, u = C.c_double(), C.c_double()
+        self._check(self.lib.mra_get_likelihood(self._h, C.byref(d), C.byref(u)))
+        return d.value, u.value
+
+    def predict(self):
+        """(mean[N], var[N]) in the caller's row order; rows outside every leaf report 0 (see
+        topology: rows that a partition drops, pyMRA/MRANode.py:222-228, 492-495)."""
+        mp = np.empty(self.P)
+        vp = np.empty(self.P)
+        self._check(self.lib.mra_get_predict(self._h, _ptr(mp), _ptr(vp)))
+        t = self.topo
+        mean = np.zeros(t.N)
+        var = np.zeros(t.N)
+        good = t.in_leaf
+        mean[t.perm[good]] = mp[good]
+        var[t.perm[good]] = vp[good]
+        return mean, var
+
+    def buffer(self, what):
+        n = C.c_int64()
+        self._check(self.lib.mra_get_buffer(self._h, what, None, 0, C.byref(n)))
+        out = np.empty(n.value)
+        self._check(self.lib.mra_get_buffer(self._h, what, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def timers(self):
+        out = np.zeros(5)
+        k = self.lib.mra_get_timers(self._h, _ptr(out), 5)
+        names = ["prior_ms", "leaf_ms", "fronts_ms", "predict_ms", "total_ms"]
+        return dict(zip(names[:k], out[:k]))
+
+    def kernel_stats(self):
+        res = []
+        for k in range(self.lib.mra_kernel_family_count()):
+            name = C.create_string_buffer(96)
+            n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+            self._check(self.lib.mra_get_kernel_stats(self._h, k, name, 96, C.byref(n), C.byref(ms), C.byref(fl)))
+            res.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+        return res
+
+    def info(self):
+        out = np.zeros(8, dtype=np.int64)
+        self.lib.mra_plan_info(self._h, _ptr(out), 8)
+        keys = ["P", "ldw", "Ka", "n_leaves", "bytes_W", "bytes_panels", "bytes_Gt", "n_nodes"]
+        return dict(zip(keys, (int(v) for v in out)))
+
+    # -- multi-GPU ---------------------------------------------------------------------------------
+    def set_reduce_level(self, level):
+        self._check(self.lib.mra_plan_set_reduce_level(self._h, int(level)))
+
+    def reduce_export(self):
+        n = C.c_int64()
+        self._check(self.lib.mra_reduce_size(self._h, C.byref(n)))
+        out = np.empty(n.value)
+        self._check(self.lib.mra_reduce_export(self._h, _ptr(out)))
+        return out
+
+    def reduce_import(self, buf):
+        b = np.ascontiguousarray(buf, dtype=np.float64)
+        self._check(self.lib.mra_reduce_import(self._h, _ptr(b)))
+
+    def comm_init(self, uid: bytes, n_ranks: int, rank: int):
+        self._check(self.lib.mra_comm_init(self._h, uid, int(n_ranks), int(rank)))
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.mra_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise MraError(rc, (lib.mra_last_error(None) or b"").decode())
+    return buf.raw
+
+
+def device_count() -> int:
+    return int(load_library().mra_device_count())
