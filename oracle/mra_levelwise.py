@@ -52,7 +52,8 @@ def _cov_callable(cov):
     return lambda a, b: np.asarray(cov(a, b), dtype=np.float64)
 
 
-def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep: bool = False):
+def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep: bool = False,
+                  reduce_level: int = -1, allreduce=None):
     """Returns dict(lik, d, u, mean[N], var[N], sd[N]) (+ intermediate buffers if keep)."""
     coords = np.asarray(locs, dtype=np.float64)
     if coords.ndim == 1:
@@ -141,17 +142,29 @@ def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep:
         Gt[i] = G
 
     # ---------------- non-leaf fronts, bottom-up ----------------------------------------------------
+    d_below = None
     for m in range(topo.n_levels - 1, -1, -1):
         cwm = int(lay.cw[m])
-        for i in range(int(topo.level_ptr[m]), int(topo.level_ptr[m + 1])):
-            if topo.node_leaf[i]:
-                continue
-            nf = int(lay.nf[m])
+        ids = [i for i in range(int(topo.level_ptr[m]), int(topo.level_ptr[m + 1])) if not topo.node_leaf[i]]
+        nf = int(lay.nf[m])
+        fronts = []
+        for i in ids:
             F = np.zeros((nf, nf))
-            F[:cwm, :cwm] = np.eye(cwm)
             for c in topo.child_list[topo.child_ptr[i]:topo.child_ptr[i + 1]]:
                 F += Gt[c]
-                Gt[c] = None if not keep else Gt[c]
+                if not keep:
+                    Gt[c] = None
+            fronts.append(F)
+        if m == reduce_level and allreduce is not None:
+            # the one exchange of the sharded path: fronts without identity + the local log-det sum
+            lo = int(topo.level_ptr[m + 1])
+            buf = np.concatenate([f.ravel() for f in fronts] + [np.array([dnode[lo:].sum()])])
+            buf = allreduce(buf)
+            fronts = [buf[t * nf * nf:(t + 1) * nf * nf].reshape(nf, nf).copy() for t in range(len(ids))]
+            d_below = float(buf[-1])
+            dnode[lo:] = 0.0
+        for i, F in zip(ids, fronts):
+            F[:cwm, :cwm] += np.eye(cwm)
             L = np.linalg.cholesky(F[:cwm, :cwm])
             Z = solve_triangular(L, F[:cwm, cwm:], lower=True).T        # na x cw  (rows-below form)
             dnode[i] = 2.0 * np.log(np.diag(L)).sum()
@@ -172,7 +185,7 @@ def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep:
                 W[r0:r1, a0:ldw] -= Xm @ Zt[i].T
 
     root = 0
-    d = float(dnode.sum())
+    d = float(dnode.sum()) + (d_below if d_below is not None else 0.0)
     u = float(Gt[root][-YB, -YB])
     mean = np.zeros(topo.N)
     v = np.zeros(topo.N)

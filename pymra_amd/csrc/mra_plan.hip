@@ -186,7 +186,6 @@ static void build_static(mra_plan* pl) {
         const int m = pl->node_level[i];
         const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
         if (!pl->leaf[i] && (rk > pl->cw[m] || rk <= 0)) throw MraError(MRA_ERR_INVALID, "non-leaf rank must be in 1..cw[level]");
-        if (!pl->leaf[i] && pl->child_ptr[i + 1] == pl->child_ptr[i]) throw MraError(MRA_ERR_INVALID, "non-leaf node without children");
     }
 
     // device arrays shared by everything

@@ -101,6 +101,7 @@ CASES = {
     "kat3":  dict(dim=1, n=100, seed=11, kern="exp", l=0.3, sig=1.0, R=1e-2, r=2,  M=3, J=3, frac=0.4),
     "c1":    dict(dim=1, n=100, seed=11, kern="m32", l=0.3, sig=1.0, R=1e-2, r=2,  M=3, J=3, frac=0.4),
     "t1000": dict(dim=1, n=1000, seed=3, kern="exp", l=0.3, sig=1.0, R=1e-2, r=2,  M=4, J=3, frac=0.4),
+    "t201":  dict(dim=1, n=201, seed=4, kern="exp", l=0.3, sig=1.0, R=1e-2, r=2,  M=3, J=3, frac=0.4),
     "kat4":  dict(dim=2, data="small", kern="exp", l=0.1, sig=1.0, R=1e-2, r=100, M=0, J=4),
     "u3":    dict(dim=2, n=10,  seed=12, kern="m32", l=0.5, sig=1.0, R=1e-6, r=2,  M=2, J=3, frac=0.7, gp=True),
     "g32":   dict(dim=2, n=32,  seed=7,  kern="exp", l=0.3, sig=1.0, R=1e-2, r=16, M=2, J=4),

@@ -1,0 +1,183 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the golden vectors that
+were produced by running the reference.  GPU only.
+
+Tolerances: north_star asks for 1e-6 relative on getLikelihood() and predict(); against the
+level-wise oracle (same algorithm) the HIP path is held to 1e-10 / 1e-9; against the reference's
+own numbers it is held to 1e-9 (lik), 1e-7 (mean) and 1e-6 (sd, ExpCovFun).  For Matern32 the
+REFERENCE's sd is itself only good to ~1e-3 relative (explicit inverses + eigh square root,
+SURVEY.md section 7 hard part 5; adjudicated in extended precision by tests/test_oracle_extended.py),
+so there the 1e-6 bar is applied against the oracle and the golden sd is checked to 2e-3.
+"""
+import numpy as np
+import pytest
+
+import _cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(built_library):
+    from pymra_amd import plan
+    if plan.device_count() < 1:
+        pytest.fail("no GPU visible: the gpu-marked tests must run on the MI355X box")
+    return plan
+
+
+def run_hip(plan_mod, cs, predict=True, topo=None):
+    t = topo if topo is not None else cs["topo"]
+    pl = plan_mod.HipPlan(t, 0)
+    pl.set_locs(cs["locs"])
+    pl.set_obs(cs["y_obs"], cs["c"]["R"])
+    s = cs["spec"]
+    pl.set_kernel(s.kind, s.l, s.sig, s.scale)
+    pl.run(True, predict)
+    d, u = pl.likelihood()
+    mean, var = pl.predict() if predict else (None, None)
+    return pl, d + u, mean, var
+
+
+@pytest.mark.parametrize("name", [n for n in K.SMALL + K.MEDIUM + K.LARGE if K.have(n)])
+def test_hip_matches_oracle_and_reference_goldens(hip, name):
+    from oracle.mra_levelwise import run_levelwise
+    cs = K.load_case(name)
+    pl, lik, mean, var = run_hip(hip, cs)
+    sd = np.sqrt(var)
+    ref = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+    hard = name == "u3"                                   # R=1e-6 Matern32: cond ~1e9
+    assert abs(lik - ref["lik"]) <= (1e-8 if hard else 1e-11) * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < (1e-8 if hard else 1e-10)
+    assert K.rel(sd, ref["sd"]) < (1e-6 if hard else 1e-9)
+    g = cs["g"]
+    if not hard:
+        assert abs(lik - g["lik"]) <= 1e-9 * abs(g["lik"])
+        assert np.max(np.abs(mean - g["mean"])) < 1e-7
+        assert K.rel(sd, g["sd"]) < (1e-6 if cs["c"]["kern"] == "exp" else 2e-3)
+    pl.close()
+
+
+@pytest.mark.parametrize("name", ["kat1", "kat2", "kat3", "kat4"])
+def test_mratree_reproduces_exact_kriging(hip, name):
+    """The reference's own unit-test identities (pyMRA/tests/unit-tests.py:22-71, 75-130) through
+    the drop-in MRATree API."""
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    cs = K.load_case(name)
+    c = cs["c"]
+    cov = lambda a, b: mt.ExpCovFun(a, b, l=c["l"])
+    tree = pymra_amd.MRATree(cs["locs"], c["r"], cov, cs["y_obs"], c["R"], M=c["M"], J=c["J"])
+    xP, sdP = tree.predict()
+    lik, mean, sd = K.kriging(cs["locs"], cs["y_obs"], cs["spec"], c["R"])
+    assert isinstance(xP, np.matrix) and xP.shape == (len(cs["locs"]), 1)
+    assert isinstance(sdP, np.ndarray) and sdP.shape == (len(cs["locs"]),)
+    L = tree.getLikelihood()
+    assert isinstance(L, np.matrix) and L.shape == (1, 1)
+    assert abs(L[0, 0] - lik) <= 1e-9 * abs(lik)
+    assert np.max(np.abs(np.asarray(xP).ravel() - mean)) < 1e-9
+    assert K.rel(sdP, sd) < 1e-8
+
+
+def test_likelihood_only_and_rerun_are_consistent(hip):
+    cs = K.load_case("g64m")
+    pl, lik, mean, var = run_hip(hip, cs)
+    pl.run(True, True)
+    d, u = pl.likelihood()
+    m2, v2 = pl.predict()
+    assert d + u == lik and np.array_equal(m2, mean) and np.array_equal(v2, var)       # bit-identical re-run
+    pl.run(True, False)
+    d, u = pl.likelihood()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
+    with pytest.raises(hip.MraError):
+        pl.predict()                                       # not computed in likelihood-only mode
+    pl.close()
+
+
+def test_observation_patterns(hip):
+    """Edge cases of the observation mask: none observed anywhere, one leaf without observations,
+    everything observed, a single observation."""
+    from oracle.mra_levelwise import run_levelwise
+    base = K.load_case("g32")
+    N = len(base["locs"])
+    rng = np.random.RandomState(0)
+    full = rng.normal(size=(N, 1))
+    t = base["topo"]
+    leaf0 = t.perm[t.node_row0[t.n_nodes - 1]:t.node_row1[t.n_nodes - 1]]
+    leaf0 = leaf0[leaf0 >= 0]
+    pats = {"all": full.copy(), "none": np.full((N, 1), np.nan), "single": np.full((N, 1), np.nan),
+            "hole": base["y_obs"].copy()}
+    pats["single"][137] = 0.7
+    pats["hole"][leaf0] = np.nan
+    for tag, y in pats.items():
+        cs = dict(base, y_obs=y)
+        pl, lik, mean, var = run_hip(hip, cs)
+        ref = run_levelwise(t, cs["locs"], cs["spec"], y, cs["c"]["R"])
+        assert abs(lik - ref["lik"]) <= 1e-11 * max(abs(ref["lik"]), 1.0), tag
+        assert np.max(np.abs(mean - ref["mean"])) < 1e-10, tag
+        assert K.rel(np.sqrt(var), ref["sd"]) < 1e-9, tag
+        if tag == "none":
+            assert lik == 0.0 and np.all(mean == 0.0)
+        pl.close()
+
+
+def test_sharded_on_one_gpu_equals_single(hip):
+    """Two 'ranks' emulated one after the other on the same GPU, exchanging the front buffer through
+    the export/import entry points (what RCCL does on the device in bench.py --gpus N)."""
+    from pymra_amd.sharding import shard_topology
+    cs = K.load_case("g64m")
+    pl, lik, mean, var = run_hip(hip, cs)
+    pl.close()
+    world = 2
+    plans, bufs = [], []
+    for r in range(world):
+        lt, red = shard_topology(cs["topo"], world, r)
+        p = hip.HipPlan(lt, 0)
+        p.set_locs(cs["locs"]); p.set_obs(cs["y_obs"], cs["c"]["R"])
+        p.set_kernel(cs["spec"].kind, cs["spec"].l, cs["spec"].sig, cs["spec"].scale)
+        p.set_reduce_level(red)
+        p.run(True, True, split=True)
+        bufs.append(p.reduce_export())
+        plans.append(p)
+    tot = bufs[0] + bufs[1]
+    m = np.zeros_like(mean); v = np.zeros_like(var)
+    for p in plans:
+        p.reduce_import(tot)
+        p.resume()
+        d, u = p.likelihood()
+        assert abs(d + u - lik) <= 1e-12 * abs(lik)
+        mm, vv = p.predict()
+        m += mm; v += vv
+        p.close()
+    assert np.max(np.abs(m - mean)) < 1e-12 and np.max(np.abs(v - var)) < 1e-13
+
+
+def test_other_device_kernels_against_oracle(hip):
+    """Matern52 / Gaussian / scaled kernels (pyMRA/MRATools.py:281-301) on the device."""
+    import pymra_amd.MRATools as mt
+    from oracle.mra_levelwise import run_levelwise
+    base = K.load_case("g32")
+    for spec in (mt.KernelSpec(mt.KIND_MATERN52, 0.25, 1.3), mt.KernelSpec(mt.KIND_GAUSSIAN, 0.05, 0.8),
+                 mt.KernelSpec(mt.KIND_MATERN32, 0.3, 1.0, scale=2.5)):
+        cs = dict(base, spec=spec)
+        pl, lik, mean, var = run_hip(hip, cs)
+        ref = run_levelwise(cs["topo"], cs["locs"], spec, cs["y_obs"], cs["c"]["R"])
+        assert abs(lik - ref["lik"]) <= 1e-9 * abs(ref["lik"])
+        assert np.max(np.abs(mean - ref["mean"])) < 1e-8
+        assert K.rel(np.sqrt(var), ref["sd"]) < 1e-7
+        pl.close()
+
+
+def test_api_errors(hip):
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("c1")
+    cov = lambda a, b: mt.Matern32(a, b, l=0.3, sig=1.0)
+    with pytest.raises(TypeError):
+        pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1, M=3, J=3)               # int R (MRANode.py:85-88)
+    with pytest.raises(AttributeError):
+        pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1e-2, M=3)                 # 1-D needs J (MRATree.py:31-33)
+    with pytest.raises(NotImplementedError):
+        pymra_amd.MRATree(cs["locs"], 2, lambda a, b: np.exp(-np.abs(a - b.T)), cs["y_obs"], 1e-2, M=3, J=3)
+    tree = pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1e-2, M=9, J=3)         # M clipped to 3
+    assert tree.M == 3 and tree.J == 3 and tree.d == 1 and tree.r == 2
+    assert abs(tree.getLikelihood()[0, 0] - float(cs["g"]["lik"])) < 1e-9
+    assert np.array_equal(tree.obs_inds, np.where(np.isfinite(cs["y_obs"]))[0])

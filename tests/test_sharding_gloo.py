@@ -1,0 +1,73 @@
+"""The N>1 path on CPU: world_size-2 (and 3) torch.distributed/gloo processes, each building its
+local shard topology and doing the ONE front all-reduce; compute is done by the NumPy oracle here
+(tests may), so what is under test is the sharding + exchange logic that bench.py --gpus N uses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _cases as K
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["MRA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MRA_ROOT"], "tests"))
+import torch, torch.distributed as dist
+import _cases as K
+from pymra_amd.sharding import shard_topology
+from oracle.mra_levelwise import run_levelwise
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cs = K.load_case(os.environ["MRA_CASE"])
+local, red = shard_topology(cs["topo"], world, rank)
+def allreduce(buf):
+    t = torch.from_numpy(np.ascontiguousarray(buf)); dist.all_reduce(t); return t.numpy()
+out = run_levelwise(local, cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"], reduce_level=red, allreduce=allreduce)
+mean = torch.from_numpy(out["mean"].copy()); var = torch.from_numpy(out["var"].copy())
+dist.all_reduce(mean); dist.all_reduce(var)          # disjoint supports: sum == concatenation
+if rank == 0:
+    np.savez(os.environ["MRA_OUT"], lik=out["lik"], mean=mean.numpy(), var=var.numpy(), P_local=local.P, red=red)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case,world", [("g32", 2), ("g64", 2), ("c1", 3)])
+def test_sharded_equals_single(tmp_path, case, world):
+    from oracle.mra_levelwise import run_levelwise
+    cs = K.load_case(case)
+    full = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "out.npz"
+    env = dict(os.environ, MRA_ROOT=K.ROOT, MRA_CASE=case, MRA_OUT=str(out), OMP_NUM_THREADS="2")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    subprocess.run(cmd, env=env, check=True, timeout=600, capture_output=True)
+    r = np.load(out)
+    assert int(r["red"]) >= 0 and int(r["P_local"]) < cs["topo"].P
+    assert abs(float(r["lik"]) - full["lik"]) <= 1e-12 * abs(full["lik"])
+    assert np.max(np.abs(r["mean"] - full["mean"])) < 1e-12
+    assert np.max(np.abs(r["var"] - full["var"])) < 1e-12
+
+
+def test_shard_bookkeeping():
+    from pymra_amd.sharding import shard_topology, choose_shard_level
+    cs = K.load_case("g64")
+    t = cs["topo"]
+    assert choose_shard_level(t, 2) == 1 and choose_shard_level(t, 4) == 1 and choose_shard_level(t, 8) == 2
+    seen = np.zeros(t.N, dtype=int)
+    for r in range(8):
+        lt, red = shard_topology(t, 8, r)
+        assert red == 1 and lt.P % 16 == 0
+        own = lt.perm[lt.in_leaf]
+        seen[own] += 1
+        # all upper nodes are replicated, children nest, knots are inside their node
+        assert lt.level_ptr[2] == t.level_ptr[2]
+        for i in range(lt.n_nodes):
+            kq = lt.knot_rows[lt.knot_ptr[i]:lt.knot_ptr[i + 1]]
+            assert np.all((kq >= lt.node_row0[i]) & (kq < lt.node_row1[i]))
+            assert np.array_equal(np.sort(lt.perm[kq]), np.sort(t.perm[t.knot_rows[t.knot_ptr[0]:t.knot_ptr[1]]])) or i > 0
+    assert np.all(seen == 1)                                # every caller row is owned by exactly one rank
