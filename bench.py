@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's metric on BASELINE.json's configuration.
+
+Workload (config.workload = "c3"): 2-D 1024x1024 grid, M=6, J=4, r0=32, Matern32(l=0.3, sig=1),
+40 % observed, R=1e-2, synthetic data by the recipe of SURVEY.md section 8(d) (seed 11).
+A "step" is one full pass of the hot path - prior for every node, posterior for every node,
+likelihood and predictive mean/variance at all 2^20 locations (everything pyMRA's MRATree
+constructor computes) - with the tree, locations and observations already resident in HBM.
+value = MRA nodes processed per second by the whole job (5461 nodes per step).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: strong scaling - the same tree, level-s subtrees sharded over the ranks, ONE RCCL all-reduce
+of the level s-1 fronts per step (pymra_amd/sharding.py); torch.distributed (gloo) is used only for
+the rendezvous, the barriers and the max-over-ranks of the timings.
+
+Extra objects in the JSON line: "roofline" (dominant kernel, hipEvent-timed inside the timed steps),
+"cpu_baseline" (N=1, rank 0: the faithful NumPy/SciPy restatement of the reference timed on a
+bounded sample of the same tree), "host" (end-to-end constructor wall-clock incl. the host tree
+build, for the getLikelihood()+predict() wall-clock half of the metric).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (= vector) peak; DESIGN.md section 5
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    "c3": dict(n=1024, M=6, J=4, r=32, kern="m32", l=0.3, sig=1.0, R=1e-2, seed=11, frac=0.4),
+    "c2": dict(n=256, M=4, J=4, r=16, kern="exp", l=0.3, sig=1.0, R=1e-2, seed=11, frac=0.4),
+}
+
+
+def make_inputs(c):
+    import pymra_amd.MRATools as mt
+    np.random.seed(c["seed"])
+    n = c["n"]
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y = np.random.normal(size=(n * n, 1))
+    oi = np.sort(np.random.choice(n * n, int(c["frac"] * n * n), replace=False))
+    y_obs = np.full((n * n, 1), np.nan)
+    y_obs[oi] = y[oi]
+    return locs, y_obs
+
+
+def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
+    """Faithful restatement of the reference's per-node work (oracle/mra_faithful.py) on a bounded
+    sample: one level-3 subtree of the same tree (85 nodes incl. 64 leaves at c3)."""
+    import pymra_amd.MRATools as mt
+    from oracle.mra_faithful import run_subtree_sample
+    cov = (lambda a, b: mt.Matern32(a, b, l=c["l"], sig=c["sig"])) if c["kern"] == "m32" else \
+          (lambda a, b: mt.ExpCovFun(a, b, l=c["l"]))
+    level = 0
+    for m in range(topo.n_levels):
+        # deepest level whose subtrees still have at least budget_nodes nodes
+        n_sub = sum(int(topo.level_ptr[k + 1] - topo.level_ptr[k]) for k in range(m, topo.n_levels)) / \
+                max(1, int(topo.level_ptr[m + 1] - topo.level_ptr[m]))
+        if n_sub >= budget_nodes:
+            level = m
+    top = int(topo.level_ptr[level])
+    n, secs, tm = run_subtree_sample(topo, locs, cov, y_obs, c["R"], top, do_gc=True)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": n / secs, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": "subtree of level-%d node %d of the same tree: %d nodes (%.1f s; prior %.1f s, posterior %.1f s, "
+                      "per-node gc.collect %.1f s as in MRANode.py:111), NumPy/SciPy default BLAS threads"
+                      % (level, top, n, secs, tm["prior"], tm["posterior"], tm["gc"]),
+            "seconds": secs, "nodes": n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--likelihood-only", action="store_true")
+    args = ap.parse_args()
+    c = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+
+    import pymra_amd.MRATools as mt
+    from pymra_amd import plan as P
+    from pymra_amd.sharding import shard_topology, sharded_run
+    from pymra_amd.topology import build_topology
+
+    if P.device_count() < 1:
+        raise SystemExit("bench.py needs an AMD GPU (libmra_hip has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+
+    # ---- set-up (untimed): inputs, tree, plan, upload ----------------------------------------------
+    t0 = time.perf_counter()
+    locs, y_obs = make_inputs(c)
+    t1 = time.perf_counter()
+    topo = build_topology(locs, c["r"], c["M"], c["J"])
+    t2 = time.perf_counter()
+    local, red = shard_topology(topo, world, rank)
+    pl = P.HipPlan(local, local_rank)
+    pl.set_locs(locs)
+    pl.set_obs(y_obs, c["R"])
+    kind = mt.KIND_MATERN32 if c["kern"] == "m32" else mt.KIND_EXP
+    pl.set_kernel(kind, c["l"], c["sig"], 1.0)
+    if world > 1:
+        uid = [P.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        pl.comm_init(uid[0], world, rank)
+    t3 = time.perf_counter()
+    predict = not args.likelihood_only
+
+    def step():
+        sharded_run(pl, red, None, True, predict)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    pl.set_option(P.MRA_OPT_KERNEL_TIMING, 1)
+    kacc = None
+    barrier()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ks = pl.kernel_stats()
+        if kacc is None:
+            kacc = ks
+        else:
+            for a, b in zip(kacc, ks):
+                a["launches"] += b["launches"]; a["ms"] += b["ms"]; a["flops"] += b["flops"]
+    barrier()
+    elapsed = time.perf_counter() - ts
+    pl.set_option(P.MRA_OPT_KERNEL_TIMING, 0)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    d, u = pl.likelihood()
+    timers = pl.timers()
+
+    # un-instrumented repeat of the same steps (event bracketing costs a little host time)
+    barrier()
+    ts = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_plain = time.perf_counter() - ts
+    if dist is not None:
+        tt = torch.tensor([elapsed_plain], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_plain = float(tt[0])
+
+    n_nodes = topo.n_nodes
+    out = None
+    if rank == 0:
+        dom = max(kacc, key=lambda k: k["ms"])
+        dom_ms = dom["ms"] / max(dom["launches"], 1)
+        dom_fl = dom["flops"] / max(dom["launches"], 1)
+        ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "avg_launch_ms": dom_ms, "flop_per_launch": dom_fl,
+                "kernels": [{"name": k["name"], "launches_per_step": k["launches"] / args.steps,
+                             "ms_per_step": k["ms"] / args.steps,
+                             "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12) if k["ms"] > 0 else 0.0}
+                            for k in kacc if k["launches"]]}
+        out = {
+            "metric": "MRA nodes/sec (prior+posterior+likelihood+predict pass), 1024^2 grid M=6 J=4 r0=32"
+                      if args.config == "c3" else "MRA nodes/sec, %s" % args.config,
+            "value": n_nodes * args.steps / elapsed_plain, "unit": "nodes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_plain / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.config, "grid": "%dx%d" % (c["n"], c["n"]), "M": c["M"], "J": c["J"],
+                       "r0": c["r"], "kernel": "Matern32" if c["kern"] == "m32" else "ExpCovFun", "l": c["l"],
+                       "frac_obs": c["frac"], "R": c["R"], "nodes": n_nodes,
+                       "mode": "likelihood" if args.likelihood_only else "likelihood+predict",
+                       "parallelism": "subtree-shard x%d, 1 all-reduce" % world if world > 1 else "single GPU"},
+            "likelihood": d + u,
+            "ms_per_step_with_kernel_events": 1e3 * elapsed / args.steps,
+            "device_phase_ms": timers,
+            "roofline": roof,
+            "host": {"input_synthesis_s": t1 - t0, "tree_build_s": t2 - t1, "plan_and_upload_s": t3 - t2},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(topo, locs, y_obs, c)
+        # end-to-end constructor wall-clock of the drop-in API (host tree build + H2D + device pass + D2H)
+        from pymra_amd import MRATree
+        np.random.seed(c["seed"]); make_inputs(c)            # RNG where the recipe leaves it
+        cov = (lambda a, b: mt.Matern32(a, b, l=c["l"], sig=c["sig"])) if c["kern"] == "m32" else \
+              (lambda a, b: mt.ExpCovFun(a, b, l=c["l"]))
+        pl.close()
+        tA = time.perf_counter()
+        tree = MRATree(locs, c["r"], cov, y_obs, c["R"], M=c["M"], J=c["J"])
+        lik = tree.getLikelihood(); xP, sdP = tree.predict()
+        out["host"]["constructor_getLikelihood_predict_wall_s"] = time.perf_counter() - tA
+        out["host"]["speedup_vs_cpu_baseline_nodes_per_s"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
