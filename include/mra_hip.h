@@ -94,6 +94,11 @@ int mra_plan_set_obs(mra_plan *plan, const double *y_perm, double R);
  * (pyMRA/MRATools.py:256-301).  params = {l, sig, scale}; value = scale * k(D; l, sig). */
 int mra_plan_set_kernel(mra_plan *plan, int kind, const double *params, int n_params);
 
+/* Diagnostics: out[i] = scale * k_kind(D[i]; l, sig) evaluated by the device code that the inference
+ * kernels inline - the device counterpart of ExpCovFun/Matern32/... applied to D = dist(locs, locs2)
+ * (pyMRA/MRATools.py:229-301). */
+int mra_eval_kernel(int kind, const double *params, int n_params, const double *D, int64_t n, double *out);
+
 /* Replaces: the `cov` callable for anything else (MRA_KERNEL_HOST): the host evaluates
  * C(S_j, Q_j) for a non-leaf node (N_j x rank, row-major, pyMRA/MRANode.py:384) or
  * C(S_j, O_j) for a leaf (N_j x n_obs_j; O_j = the leaf's observed rows in ascending row order)
@@ -127,6 +132,7 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
  * (0 .. mra_kernel_family_count()-1), its name, the number of launches, their summed device
  * milliseconds and the algorithmic flop count of those launches. */
 #define MRA_OPT_KERNEL_TIMING  1
+#define MRA_OPT_FUSED          2   /* 1 (default): fused cascade kernels on regular trees; 0: level-by-level kernels */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 int mra_kernel_family_count(void);
 int mra_get_kernel_stats(mra_plan *plan, int which, char *name, int name_cap, int *launches, double *ms,

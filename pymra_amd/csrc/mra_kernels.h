@@ -52,26 +52,79 @@ struct KernelParams {
     int kind;
     int d;
     double l, sig, scale;
+    // derived on the host (derive_kernel_params): value = amp * (1 + a1 t + a2 t^2) * exp(-t)
+    //   mode 0: t = c * D / l   (ExpCovFun: c=1,a1=a2=0; Matern32: c=sqrt3,a1=1; Matern52: c=sqrt5,a1=1,a2=1/3)
+    //   mode 1: t = D^2 / (2 l^2)   (GaussianCovFun)          mode 2: [D == 0]   (Iden)
+    int mode;
+    double c_inv_l, inv_2l2, a1, a2, amp;
 };
+#define MRA_FAR_AWAY 1.0e150   /* coordinate of a phantom knot: every kernel gives exactly 0 there */
 
+// exp(-t), t >= 0: t = k ln2 + r, |r| <= ln2/2, degree-13 Taylor (remainder < 4e-18), v_ldexp_f64.
+// The ocml exp()/sqrt() are an order of magnitude more instructions (denormal/NaN/overflow care that
+// cannot occur here) and made the covariance evaluation the bottleneck of every kernel using it.
+__device__ __forceinline__ double exp_neg(double t) {
+    t = fmin(t, 1100.0);
+    const double kf = __builtin_rint(t * 1.4426950408889634074);
+    double r = __builtin_fma(kf, 6.93147180369123816490e-01, -t);      // k*ln2_hi - t
+    r = __builtin_fma(kf, 1.90821492927058770002e-10, r);              // + k*ln2_lo  ->  r = -(t - k ln2)
+    double p = 1.6059043836821613e-10;                                  // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.388888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, -(int)kf);
+}
+
+// sqrt(x), x >= 0 finite: v_rsq_f64 seed + two Goldschmidt steps (<= 1 ulp)
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1.0e-300));      // x == 0 stays 0 through every step below
+    double g = x * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    // one residual correction: g += (x - g*g) * h
+    h = __builtin_fma(h, e, h);
+    const double res = __builtin_fma(-g, g, x);
+    return __builtin_fma(res, h, g);
+}
+
+// value of the kernel at squared distance D2 (the reference evaluates the same formulas on
+// D = cdist(...), pyMRA/MRATools.py:265-301; differences are at the 1-2 ulp level).  Straight-line
+// code: the only branches are on wave-uniform kernel parameters.
+template <int MODE>
+__device__ __forceinline__ double cov_of_dist2(const KernelParams& kp, double D2) {
+    if (MODE == 2) return (D2 == 0.0) ? kp.amp : 0.0;
+    const double t = (MODE == 1) ? D2 * kp.inv_2l2 : sqrt_pos(D2) * kp.c_inv_l;
+    const double poly = __builtin_fma(__builtin_fma(kp.a2, t, kp.a1), t, 1.0);
+    return kp.amp * (poly * exp_neg(t));
+}
 __device__ __forceinline__ double cov_of_dist(const KernelParams& kp, double D) {
-    double v;
-    switch (kp.kind) {
-        case 0:  v = exp(-D / kp.l); break;
-        case 1: { double t = 1.7320508075688772 * D / kp.l; v = kp.sig * ((1.0 + t) * exp(-t)); } break;
-        case 2: { double t = 2.23606797749979 * D / kp.l; double s = D / kp.l;
-                  v = kp.sig * ((1.0 + t + (5.0 / 3.0) * (s * s)) * exp(-t)); } break;
-        case 3:  v = kp.sig * exp(-(D * D) / (2.0 * (kp.l * kp.l))); break;
-        default: v = (D == 0.0) ? 1.0 : 0.0; break;
-    }
-    return kp.scale * v;
+    return kp.mode == 0 ? cov_of_dist2<0>(kp, D * D) : (kp.mode == 1 ? cov_of_dist2<1>(kp, D * D) : cov_of_dist2<2>(kp, D * D));
 }
 
 template <int DIM>
-__device__ __forceinline__ double pair_dist(const double* __restrict__ xa, const double* __restrict__ xb) {
-    if (DIM == 1) return fabs(xa[0] - xb[0]);
-    double dx = xa[0] - xb[0], dy = xa[1] - xb[1];
-    return sqrt(dx * dx + dy * dy);
+__device__ __forceinline__ double pair_dist2(const double* __restrict__ xa, const double* __restrict__ xb) {
+    if (DIM == 1) { const double dx = xa[0] - xb[0]; return dx * dx; }
+    const double dx = xa[0] - xb[0], dy = xa[1] - xb[1];
+    return dx * dx + dy * dy;
+}
+
+// diagnostics / tests: kernel values for an array of distances
+__global__ void k_eval_kernel(const double* __restrict__ D, double* __restrict__ out, long n, KernelParams kp) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cov_of_dist(kp, D[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -92,7 +145,7 @@ struct GemmProb {
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
 
-template <int EPI, int DIM>
+template <int EPI, int DIM, int MODE>
 __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp) {
     const GemmProb pb = probs[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -133,6 +186,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
     // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
     auto emit = [&](d4 acc, int mb, int nb, int bcol) {
         const int col = nb + r;
+        double xb[DIM];
+        if (EPI == EPI_COV) {
+            const long bc = bcol < 0 ? 0 : bcol;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xb[c] = pb.XB[bc * DIM + c];
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = mb + q + 4 * s;
@@ -141,11 +200,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             if (EPI == EPI_SET) v = acc[s];
             else if (EPI == EPI_SUB) v = *cp - acc[s];
             else if (EPI == EPI_COV) {
-                if (bcol < 0) v = 0.0;
-                else {
-                    double D = pair_dist<DIM>(pb.XA + (long)row * DIM, pb.XB + (long)bcol * DIM);
-                    v = cov_of_dist(kp, D) - acc[s];
-                }
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
+                v = (bcol < 0) ? 0.0 : cv;
             } else {
                 v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
             }
@@ -328,6 +384,282 @@ __global__ __launch_bounds__(256) void k_trsm_rows(const TrsmNode* __restrict__ 
         ssq += __shfl_xor(ssq, 32, 64);
         if (q == 0) var[tile_row0[t] + r] += ssq;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  X = R L^{-T} on 16-row tiles, second generation: L and the inverted diagonal blocks are staged in
+//  LDS once per workgroup, the solved tiles X_kb stay in registers, and every global access moves
+//  32 contiguous bytes per lane.
+//
+//  "vec" tile layout: element j of lane (r,q) is tile[r][4q + j].  It is the B operand of k-step j
+//  (k <-> column 4q+j).  The A operand of k-step j is then Amat[pi(r)][4q + j] with the row
+//  permutation pi(rho) = 4 (rho & 3) + (rho >> 2): with it the accumulator (row rho = q + 4 s) lands
+//  in vec layout again (column pi(q + 4 s) = 4 q + s), so solved tiles chain as B operands and are
+//  stored with 32-byte accesses.
+// ------------------------------------------------------------------------------------------------
+struct Trsm2Prob {
+    const double* L;      // nt*16 square lower-triangular factor, row-major
+    const double* invd;   // nt inverted 16x16 diagonal blocks (row-major, 256 doubles each)
+    double* X;            // first row of the row range, row-major
+    double* var;          // nullptr or per-row accumulator (+= rowsumsq(X)), indexed from the first row
+    long ldL, ldx;
+    int nt;               // column tiles
+    int ntiles;           // 16-row tiles
+};
+
+__device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
+
+template <int NTMAX>
+__global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict__ probs, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Trsm2Prob pb = probs[blockIdx.y];
+    const int t_begin = blockIdx.x * tiles_per_wg;
+    if (t_begin >= pb.ntiles) return;
+    const int t_end = min(pb.ntiles, t_begin + tiles_per_wg);
+    const int nt = pb.nt;
+    const int ntri = nt * (nt - 1) / 2;
+    // ---- stage L (strictly-lower tiles, index jb(jb-1)/2+kb) and invd (after them) in LDS
+    for (int e = threadIdx.x; e < (ntri + nt) * 128; e += blockDim.x) {     // 128 16-byte chunks per tile
+        const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
+        const double* src;
+        if (tile < ntri) {
+            int jb = 1;
+            while ((jb + 1) * jb / 2 <= tile) ++jb;
+            const int kb = tile - jb * (jb - 1) / 2;
+            src = pb.L + (long)(jb * 16 + row) * pb.ldL + kb * 16 + c2;
+        } else {
+            src = pb.invd + (long)(tile - ntri) * 256 + row * 16 + c2;
+        }
+        *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int nwave = blockDim.x >> 6;
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    for (int t = t_begin + wave; t < t_end; t += nwave) {
+        double* xp = pb.X + (long)t * 16 * pb.ldx + (long)r * pb.ldx + 4 * q;
+        d4 x[NTMAX];
+        double ssq = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < NTMAX; ++jb) {
+            if (jb < nt) {
+                d4 acc = *(const d4*)(xp + jb * 16);
+                d4 upd = zero;
+#pragma unroll
+                for (int kb = 0; kb < jb; ++kb) {
+                    const d4 a = *(const d4*)(lds + (jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) upd = mfma16(a[j], x[kb][j], upd);
+                }
+                acc -= upd;
+                const d4 ia = *(const d4*)(lds + (ntri + jb) * 256 + prow * 16 + 4 * q);
+                d4 xx = zero;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], acc[j], xx);
+                x[jb] = xx;
+                *(d4*)(xp + jb * 16) = xx;
+                ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
+            }
+        }
+        if (pb.var) {
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (q == 0) pb.var[(long)t * 16 + r] += ssq;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Fused prior cascade ("regular" trees: every non-leaf level has the same knot-block width
+//  CWT*16 and all leaves sit on the last level).
+//
+//  One wave owns 16 rows and walks down the levels with the whitened basis tiles of all coarser
+//  levels in registers (vec layout, see k_trsm_rows2):
+//      R^m   = kernel(x_i, knots_m) - sum_{k<m} W^k[i] Wk_m[:, block k]^T        (MRANode.py:73-80, 384)
+//      W^m   = R^m L_m^{-T}                                                       (MRANode.py:385-387)
+//  The per-node operands (knot coordinates kx, knot rows of the coarser bases Wk, factor L, inverted
+//  diagonal blocks) are small, shared by every row of the node and come through L1/L2.
+//  FULL mode: rows are a contiguous tile, all levels 0..mlast are processed and W is written once.
+//  KNOT mode: rows are the knots of one level-(mlast+1) node (16 per tile, by index); the output is
+//  that node's Wk rows (its kInv then comes from k_knot_kinv, its factor from k_panel_chol).
+// ------------------------------------------------------------------------------------------------
+struct CascadeLevel {
+    const double* kx;     // [node][cw][DIM] knot coordinates
+    const int* kvalid;    // [node][cw] 1 = real knot, 0 = phantom
+    const double* Wk;     // [node][cw][m*cw] knot rows of the coarser whitened bases, level-major columns
+    const double* L;      // [node][cw][cw]
+    const double* invd;   // [node][cwt][256]
+};
+struct CascadeArgs {
+    CascadeLevel lev[8];
+    const double* X;          // coordinates of all rows [P][DIM]
+    double* W;                // FULL: whitened basis, ldw
+    long ldw;
+    int coff[8];              // column offset of level m's block in W
+    const int* tile_rows;     // KNOT: [ntiles][16] row numbers (-1: phantom knot)
+    const int* tile_chain;    // [ntiles][8]  node slot per level
+    const long* tile_row0;    // FULL: first row of each tile
+    const int* tile_knot0;    // KNOT: index of the tile's first knot inside its node (multiple of 16)
+    double* Wk_out;           // KNOT: [node][cw][(mlast+1)*cw] of level mlast+1
+    const long* wg_tile0;     // per workgroup: first tile and number of tiles (<= 8), all sharing one chain
+    const int* wg_ntiles;
+    long n_wg;
+    int mlast;
+    int knot_mode;
+};
+
+template <int CWT, int NLMAX, int DIM, int MODE>
+__global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelParams kp) {
+    // One workgroup = up to 8 row tiles that share the same node on every level (same leaf / same
+    // knot set), one tile per wave.  Per level the node's operands (Wk, strictly-lower tiles of L,
+    // inverted diagonal blocks) are staged in LDS once and read by all waves.
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CW = CWT * 16;
+    constexpr int NTRI = CWT * (CWT - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long t0 = ar.wg_tile0[blockIdx.x];
+    const int nt_wg = ar.wg_ntiles[blockIdx.x];
+    const bool active = wave < nt_wg;
+    const long t = t0 + (active ? wave : 0);
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    long myrow;
+    bool phantom_row = false;
+    if (ar.knot_mode) {
+        const int rr = ar.tile_rows[t * 16 + r];
+        phantom_row = rr < 0;
+        myrow = phantom_row ? 0 : rr;
+    } else {
+        myrow = ar.tile_row0[t] + r;
+    }
+    double xr[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
+    const int* chain = ar.tile_chain + t0 * 8;          // identical for every tile of the workgroup
+    d4 w[NLMAX][CWT];
+#pragma unroll
+    for (int m = 0; m < NLMAX; ++m) {
+        if (m <= ar.mlast) {
+            const int slot = chain[m];
+            const CascadeLevel lv = ar.lev[m];
+            const double* Wk = lv.Wk + (long)slot * CW * (m * CW);
+            const double* kx = lv.kx + (long)slot * CW * DIM;
+            const double* Lm = lv.L + (long)slot * CW * CW;
+            const double* inv = lv.invd + (long)slot * CWT * 256;
+            // ---- stage this level's operands: tiles [jb][k*CWT+kt] of Wk, then L (jb>kb), then invd
+            const int nwk = CWT * m * CWT;
+            __syncthreads();
+            for (int e = threadIdx.x; e < (nwk + NTRI + CWT) * 128; e += blockDim.x) {
+                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
+                const double* src;
+                if (tile < nwk) {
+                    const int jb = tile / (m * CWT), kk = tile % (m * CWT);
+                    src = Wk + (long)(jb * 16 + row) * (m * CW) + kk * 16 + c2;
+                } else if (tile < nwk + NTRI) {
+                    const int tt = tile - nwk;
+                    int jb = 1;
+                    while ((jb + 1) * jb / 2 <= tt) ++jb;
+                    const int kb = tt - jb * (jb - 1) / 2;
+                    src = Lm + (long)(jb * 16 + row) * CW + kb * 16 + c2;
+                } else {
+                    src = inv + (long)(tile - nwk - NTRI) * 256 + row * 16 + c2;
+                }
+                *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int jb = 0; jb < CWT; ++jb) {
+                    d4 acc = zero;
+#pragma unroll
+                    for (int k = 0; k < NLMAX; ++k) {
+                        if (k < m) {
+#pragma unroll
+                            for (int kt = 0; kt < CWT; ++kt) {
+                                const d4 a = *(const d4*)(lds + (jb * (m * CWT) + k * CWT + kt) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc = mfma16(a[j], w[k][kt][j], acc);
+                            }
+                        }
+                    }
+                    d4 res;
+                    {
+                        double kc[4 * DIM];                     // coordinates of this lane's 4 knots (phantoms: far away)
+                        const double* kp4 = kx + (long)(jb * 16 + 4 * q) * DIM;
+#pragma unroll
+                        for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM)) - acc[j];
+                    }
+                    d4 upd = zero;
+#pragma unroll
+                    for (int kb = 0; kb < CWT; ++kb) {
+                        if (kb < jb) {
+                            const d4 a = *(const d4*)(lds + (nwk + jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) upd = mfma16(a[j], w[m][kb][j], upd);
+                        }
+                    }
+                    res -= upd;
+                    const d4 ia = *(const d4*)(lds + (nwk + NTRI + jb) * 256 + prow * 16 + 4 * q);
+                    d4 xx = zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], res[j], xx);
+                    w[m][jb] = xx;
+                }
+            }
+        }
+    }
+    if (!active) return;
+    // ---- outputs
+    if (ar.knot_mode) {
+        const int mo = ar.mlast + 1;
+        const int slotk = chain[mo];
+        const int krow = ar.tile_knot0[t] + r;
+        double* o = ar.Wk_out + ((long)slotk * CW + krow) * (mo * CW);
+#pragma unroll
+        for (int k = 0; k < NLMAX; ++k) {
+            if (k < mo) {
+#pragma unroll
+                for (int kt = 0; kt < CWT; ++kt) {
+                    d4 v = phantom_row ? zero : w[k][kt];
+                    *(d4*)(o + (k * CWT + kt) * 16 + 4 * q) = v;
+                }
+            }
+        }
+    } else {
+        double* o = ar.W + myrow * ar.ldw;
+#pragma unroll
+        for (int m = 0; m < NLMAX; ++m) {
+            if (m <= ar.mlast) {
+#pragma unroll
+                for (int jb = 0; jb < CWT; ++jb) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = w[m][jb];
+            }
+        }
+    }
+}
+
+// kInv of the nodes of one level from their knots: cov(knots, knots) - Wk Wk^T, identity on phantoms
+template <int DIM>
+__global__ void k_knot_kinv(const double* __restrict__ kx, const int* __restrict__ kvalid, const double* __restrict__ Wk,
+                            double* __restrict__ Lp, int cw, int K, KernelParams kp) {
+    const long node = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cw * cw) return;
+    const int a = e / cw, b = e % cw;
+    const int* kv = kvalid + node * cw;
+    double v = (a == b) ? 1.0 : 0.0;
+    if (kv[a] && kv[b]) {
+        const double* xa = kx + (node * cw + a) * DIM;
+        const double* xb = kx + (node * cw + b) * DIM;
+        const double* wa = Wk + (node * cw + a) * K;
+        const double* wb = Wk + (node * cw + b) * K;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += wa[k] * wb[k];
+        v = (kp.mode == 0 ? cov_of_dist2<0>(kp, pair_dist2<DIM>(xa, xb)) : (kp.mode == 1 ? cov_of_dist2<1>(kp, pair_dist2<DIM>(xa, xb)) : cov_of_dist2<2>(kp, pair_dist2<DIM>(xa, xb)))) - s;
+    }
+    Lp[(node * cw + a) * cw + b] = v;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -19,6 +19,20 @@
 #include <string>
 #include <vector>
 
+static void derive_kernel_params(KernelParams& kp) {
+    kp.mode = 0; kp.a1 = 0.0; kp.a2 = 0.0; kp.amp = kp.scale * kp.sig;
+    kp.inv_2l2 = 1.0 / (2.0 * (kp.l * kp.l));
+    double c = 1.0;
+    switch (kp.kind) {
+        case 0: kp.amp = kp.scale; break;                       // ExpCovFun has no sig
+        case 1: c = 1.7320508075688772; kp.a1 = 1.0; break;
+        case 2: c = 2.23606797749979; kp.a1 = 1.0; kp.a2 = 1.0 / 3.0; break;
+        case 3: kp.mode = 1; break;
+        default: kp.mode = 2; kp.amp = kp.scale; break;
+    }
+    kp.c_inv_l = c / kp.l;
+}
+
 #define MRA_VERSION_STR "mra_hip 0.1 (gfx950)"
 
 static thread_local std::string g_last_error;
@@ -45,7 +59,7 @@ enum KFam {
     KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
 };
 static const char* kfam_name[KF_COUNT] = {
-    "k_gemm_nt<COV> prior resid", "k_panel_chol prior", "k_trsm_rows prior", "k_gemm_nt<COV> leaf resid",
+    "k_gemm_nt<COV> prior resid", "k_panel_chol prior", "k_trsm_rows prior / fused prior cascade", "k_gemm_nt<COV> leaf resid",
     "k_panel_chol leaf", "k_gemm_nt<SET> leaf syrk", "k_gemm_nt<SUB> leaf update", "k_panel_chol front",
     "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update", "small kernels"};
 
@@ -88,6 +102,8 @@ struct LevelData {
     DevVec<KinvProb> gKinv;
     DevVec<PanelProb> gPriorChol, gFrontChol;
     DevVec<TrsmNode> gTrsmPrior, gTrsmPost;
+    DevVec<Trsm2Prob> gTrsm2Prior, gTrsm2Post;
+    long max_tiles = 0;
     DevVec<int> tile_node;
     DevVec<long> tile_row0;
     long ntiles = 0;
@@ -131,11 +147,28 @@ struct mra_plan {
     DevVec<int> obs_idx;
     DevVec<LeafProb> gLeaf;
     DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
-    DevVec<PanelProb> gLeafCholFull, gLeafCholLik;
+    DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
+    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik;
+    int leaf_max_tiles_full = 0, leaf_max_tiles_lik = 0;
     DevVec<AsmChild> asmKids;
     long leaf_max_rows = 0;
     int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
+    // fused ("regular tree") path
+    bool regular = false, use_fused = true;
+    int NL = 0, CWT = 0;
+    struct FusedLevel {
+        DevVec<double> kx, Wk;
+        DevVec<int> kvalid, kt_rows, kt_chain, kt_knot0, kt_wgn;
+        DevVec<long> kt_wg0;
+        long n_ktiles = 0, n_kwg = 0;
+    };
+    std::vector<FusedLevel> fl;
+    DevVec<long> ft_row0, ft_wg0;
+    DevVec<int> ft_chain, ft_wgn;
+    long n_ftiles = 0, n_fwg = 0;
+    size_t cascade_lds = 0;
+    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the cascade kernels
     // host cov staging (MRA_KERNEL_HOST)
     std::vector<long> cov_off;           // per node offset into covsrc
     std::vector<double> cov_host, covdiag_host;
@@ -263,6 +296,7 @@ static void build_static(mra_plan* pl) {
         std::vector<KinvProb> kinv(nn);
         std::vector<PanelProb> pch(nn), fch(nn);
         std::vector<TrsmNode> tpr(nn), tpo(nn);
+        std::vector<Trsm2Prob> t2pr(nn), t2po(nn);
         std::vector<AsmProb> as(nn);
         std::vector<int> tnode;
         std::vector<long> trow;
@@ -288,6 +322,9 @@ static void build_static(mra_plan* pl) {
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
             tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
             lv.fl_trsm += (double)nr * lv.cw * lv.cw;
+            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16)};
+            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16)};
+            lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
             fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
             lv.fl_fchol += (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw;
@@ -325,10 +362,90 @@ static void build_static(mra_plan* pl) {
         lv.gResid.upload(resid); lv.gSchur.upload(schur); lv.gUpdate.upload(upd); lv.gKinv.upload(kinv);
         lv.gPriorChol.upload(pch); lv.gFrontChol.upload(fch); lv.gTrsmPrior.upload(tpr); lv.gTrsmPost.upload(tpo);
         lv.gAsm.upload(as);
+        lv.gTrsm2Prior.upload(t2pr); lv.gTrsm2Post.upload(t2po);
         lv.ntiles = (long)tnode.size();
         lv.tile_node.upload(tnode); lv.tile_row0.upload(trow);
     }
     pl->asmKids.upload(kids);
+
+    // ---- fused path eligibility: uniform block width on all non-leaf levels, leaves only on the last level
+    pl->regular = false;
+    const int NL = L - 1;
+    if (NL >= 1 && NL <= 8) {
+        bool ok = true;
+        for (int m = 0; m < NL && ok; ++m) {
+            if (pl->cw[m] != pl->cw[0]) ok = false;
+            for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1] && ok; ++i) if (pl->leaf[i]) ok = false;
+        }
+        for (long i = pl->level_ptr[NL]; i < pl->level_ptr[NL + 1] && ok; ++i) if (!pl->leaf[i]) ok = false;
+        const int cwt = pl->cw[0] / 16;
+        if (cwt != 1 && cwt != 2 && cwt != 4) ok = false;
+        if (cwt * NL > 16) ok = false;                       // register budget of the cascade kernels
+        if (ok) { pl->regular = true; pl->NL = NL; pl->CWT = cwt; }
+    }
+    if (pl->regular) {
+        const int cw = pl->cw[0];
+        pl->fl.clear();
+        pl->fl.resize(pl->NL);
+        auto chain_of = [&](int node, int* out) {            // slots of the ancestors (and the node itself)
+            for (int k = 0; k < 8; ++k) out[k] = 0;
+            int i = node;
+            while (i >= 0) {
+                if (!pl->leaf[i]) out[pl->node_level[i]] = pl->node_slot[i];
+                i = pl->parent[i];
+            }
+        };
+        for (int m = 0; m < pl->NL; ++m) {
+            mra_plan::FusedLevel& f = pl->fl[m];
+            const LevelData& lv = pl->lev[m];
+            const size_t nn = lv.nodes.size();
+            f.kx.alloc(nn * (size_t)cw * pl->d);
+            f.Wk.alloc(std::max<size_t>(nn * (size_t)cw * (m * cw), 1));
+            std::vector<int> kv(nn * (size_t)cw), rows, chain, knot0, wgn;
+            std::vector<long> wg0;
+            for (size_t sl = 0; sl < nn; ++sl) {
+                const int i = lv.nodes[sl];
+                const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+                for (int c = 0; c < cw; ++c) kv[sl * cw + c] = c < rk ? 1 : 0;
+                int ch[8];
+                chain_of(i, ch);
+                wg0.push_back((long)knot0.size()); wgn.push_back(cw / 16);
+                for (int tt = 0; tt < cw / 16; ++tt) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = tt * 16 + r;
+                        rows.push_back(c < rk ? (int)pl->knot_rows[pl->knot_ptr[i] + c] : -1);
+                    }
+                    for (int k = 0; k < 8; ++k) chain.push_back(ch[k]);
+                    knot0.push_back(tt * 16);
+                }
+            }
+            f.kvalid.upload(kv); f.kt_rows.upload(rows); f.kt_chain.upload(chain); f.kt_knot0.upload(knot0);
+            f.n_ktiles = (long)knot0.size();
+            f.kt_wg0.upload(wg0); f.kt_wgn.upload(wgn); f.n_kwg = (long)wg0.size();
+        }
+        std::vector<long> r0s, fwg0;
+        std::vector<int> chains, fwgn;
+        for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+            const int i = pl->leaf_nodes[t];
+            int ch[8];
+            chain_of(i, ch);
+            for (long p = pl->row0[i]; p < pl->row1[i]; p += 16) {
+                if (((p - pl->row0[i]) / 16) % pl->cascade_wpw == 0) {
+                    fwg0.push_back((long)r0s.size());
+                    fwgn.push_back((int)std::min<long>(pl->cascade_wpw, (pl->row1[i] - p) / 16));
+                }
+                r0s.push_back(p);
+                for (int k = 0; k < 8; ++k) chains.push_back(ch[k]);
+            }
+        }
+        pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains);
+        pl->n_ftiles = (long)r0s.size();
+        pl->ft_wg0.upload(fwg0); pl->ft_wgn.upload(fwgn); pl->n_fwg = (long)fwg0.size();
+        {
+            const int cwt = pl->CWT, mmax = pl->NL - 1;
+            pl->cascade_lds = (size_t)(cwt * mmax * cwt + cwt * (cwt - 1) / 2 + cwt) * 2048;
+        }
+    }
 }
 
 // leaf descriptors: depend on which rows are observed
@@ -364,7 +481,9 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
     std::vector<LeafProb> lp(nl);
     std::vector<GemmProb> gr(nl), gs(nl), gu(nl);
-    std::vector<PanelProb> pf(nl), pk(nl);
+    std::vector<PanelProb> pf(nl), pk(nl), pc(nl);
+    std::vector<Trsm2Prob> tf(nl), tk(nl);
+    pl->leaf_max_tiles_full = pl->leaf_max_tiles_lik = 0;
     pl->fl_leaf_resid = pl->fl_leaf_chol = pl->fl_leaf_chol_lik = pl->fl_leaf_syrk = pl->fl_leaf_update = 0;
     for (size_t t = 0; t < nl; ++t) {
         const int i = pl->leaf_nodes[t];
@@ -388,6 +507,11 @@ static void build_leaf(mra_plan* pl, const double* y) {
         double* inv = pl->leafInv.p + pl->leaf_ioff[t];
         pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
         pk[t] = PanelProb{Pn, inv, nop, (nop + na) / 16, nop / 16, i};
+        pc[t] = PanelProb{Pn, inv, nop, nop / 16, nop / 16, i};
+        tf[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, (int)((na + nr) / 16)};
+        tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16};
+        pl->leaf_max_tiles_full = std::max(pl->leaf_max_tiles_full, (int)((na + nr) / 16));
+        pl->leaf_max_tiles_lik = std::max(pl->leaf_max_tiles_lik, na / 16);
         pl->fl_leaf_chol += (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop;
         pl->fl_leaf_chol_lik += (double)nop * nop * nop / 3.0 + (double)na * nop * nop;
         GemmProb s{};
@@ -402,7 +526,8 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->fl_leaf_update += 2.0 * nr * na * nop;
     }
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
-    pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk);
+    pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
+    pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,14 +563,115 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
     for (size_t off = 0; off < nprob; off += 65535) {
         const unsigned gy = (unsigned)std::min<size_t>(65535, nprob - off);
         dim3 grid(gx, gy);
-        if (pl->d == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 1>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
-        else hipLaunchKernelGGL((k_gemm_nt<EPI, 2>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+        const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
+        if (pl->d == 1) {
+            if (mode == 0) hipLaunchKernelGGL((k_gemm_nt<EPI, 1, 0>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+            else if (mode == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 1, (EPI == EPI_COV ? 1 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+            else hipLaunchKernelGGL((k_gemm_nt<EPI, 1, (EPI == EPI_COV ? 2 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((k_gemm_nt<EPI, 2, 0>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+            else if (mode == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 2, (EPI == EPI_COV ? 1 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+            else hipLaunchKernelGGL((k_gemm_nt<EPI, 2, (EPI == EPI_COV ? 2 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+        }
     }
 }
 
 static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob) {
     if (!nprob) return;
     hipLaunchKernelGGL(k_panel_chol, dim3((unsigned)nprob), dim3(256), 0, pl->stream, probs, pl->dnode.p, pl->errflag.p);
+}
+
+// row-tile triangular solve with L in LDS; returns false when nt is too large for the LDS path
+static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int nt, long max_tiles, int tiles_per_wg) {
+    if (!nprob || max_tiles <= 0 || nt <= 0) return true;
+    if (nt > 12) return false;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {       // dynamic LDS above 64 KiB has to be requested per kernel
+        hipFuncSetAttribute((const void*)k_trsm_rows2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_trsm_rows2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_trsm_rows2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_trsm_rows2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_attr_set = true;
+    }
+    const size_t lds = (size_t)(nt * (nt - 1) / 2 + nt) * 2048;
+    const unsigned gx = (unsigned)((max_tiles + tiles_per_wg - 1) / tiles_per_wg);
+    for (size_t off = 0; off < nprob; off += 65535) {
+        dim3 grid(gx, (unsigned)std::min<size_t>(65535, nprob - off));
+        if (nt <= 2) hipLaunchKernelGGL((k_trsm_rows2<2>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
+        else if (nt <= 4) hipLaunchKernelGGL((k_trsm_rows2<4>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
+        else if (nt <= 8) hipLaunchKernelGGL((k_trsm_rows2<8>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
+        else hipLaunchKernelGGL((k_trsm_rows2<12>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
+    }
+    return true;
+}
+
+template <int CWT, int NLMAX, int DIM, int MODE>
+static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw), pl->cascade_lds, pl->stream, ar, pl->kp);
+}
+template <int CWT, int NLMAX>
+static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
+    if (ar.n_wg <= 0) return;
+    const int mode = pl->kp.mode;
+    if (pl->d == 1) {
+        if (mode == 0) launch_cascade_inst<CWT, NLMAX, 1, 0>(pl, ar);
+        else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 1, 1>(pl, ar);
+        else launch_cascade_inst<CWT, NLMAX, 1, 2>(pl, ar);
+    } else {
+        if (mode == 0) launch_cascade_inst<CWT, NLMAX, 2, 0>(pl, ar);
+        else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 2, 1>(pl, ar);
+        else launch_cascade_inst<CWT, NLMAX, 2, 2>(pl, ar);
+    }
+}
+static void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) {
+    if (pl->CWT == 1) launch_cascade<1, 8>(pl, ar);
+    else if (pl->CWT == 2) launch_cascade<2, 8>(pl, ar);
+    else launch_cascade<4, 4>(pl, ar);
+}
+
+// whole prior of a regular tree: per level a tiny knot pass (knot rows cascade -> kInv -> Cholesky),
+// then ONE cascade over all leaf row tiles that writes W once
+static void run_prior_fused(mra_plan* pl) {
+    const int cw = pl->cw[0];
+    CascadeArgs base{};
+    for (int m = 0; m < pl->NL; ++m) {
+        base.lev[m].kx = pl->fl[m].kx.p; base.lev[m].kvalid = pl->fl[m].kvalid.p; base.lev[m].Wk = pl->fl[m].Wk.p;
+        base.lev[m].L = pl->lev[m].Lp.p; base.lev[m].invd = pl->lev[m].invP.p;
+        base.coff[m] = pl->coff[m];
+    }
+    base.X = pl->X.p; base.W = pl->W.p; base.ldw = pl->ldw;
+    for (int m = 0; m < pl->NL; ++m) {
+        LevelData& lv = pl->lev[m];
+        const size_t nn = lv.nodes.size();
+        if (m > 0) {
+            KTimer kt(pl, KF_PRIOR_RESID, 0);
+            CascadeArgs ar = base;
+            ar.knot_mode = 1; ar.mlast = m - 1; ar.n_wg = pl->fl[m].n_kwg;
+            ar.wg_tile0 = pl->fl[m].kt_wg0.p; ar.wg_ntiles = pl->fl[m].kt_wgn.p;
+            ar.tile_rows = pl->fl[m].kt_rows.p; ar.tile_chain = pl->fl[m].kt_chain.p; ar.tile_knot0 = pl->fl[m].kt_knot0.p;
+            ar.Wk_out = pl->fl[m].Wk.p;
+            launch_cascade_any(pl, ar);
+        }
+        {
+            KTimer kt(pl, KF_MISC, 0);
+            dim3 grid((unsigned)((cw * cw + 255) / 256), (unsigned)nn);
+            if (pl->d == 1) hipLaunchKernelGGL((k_knot_kinv<1>), grid, dim3(256), 0, pl->stream, pl->fl[m].kx.p, pl->fl[m].kvalid.p, pl->fl[m].Wk.p, lv.Lp.p, cw, m * cw, pl->kp);
+            else hipLaunchKernelGGL((k_knot_kinv<2>), grid, dim3(256), 0, pl->stream, pl->fl[m].kx.p, pl->fl[m].kvalid.p, pl->fl[m].Wk.p, lv.Lp.p, cw, m * cw, pl->kp);
+        }
+        { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
+    }
+    {
+        double fl = 0;
+        for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_resid + pl->lev[m].fl_trsm;
+        KTimer kt(pl, KF_PRIOR_TRSM, fl);
+        CascadeArgs ar = base;
+        ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.n_wg = pl->n_fwg;
+        ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
+        ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p;
+        launch_cascade_any(pl, ar);
+    }
 }
 
 static void phase_mark(mra_plan* pl, int k) { hipEventRecord(pl->ev[k], pl->stream); }
@@ -514,6 +740,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
             if (!nn) continue;
             {
                 KTimer kt(pl, KF_PRED_TRSM, lv.fl_trsm);
+                if (!launch_trsm2(pl, lv.gTrsm2Post.p, nn, lv.cwt, lv.max_tiles, 32))
                 hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
                                    lv.gTrsmPost.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw,
                                    lv.c0, pl->var.p);
@@ -594,7 +821,9 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                            (long)pl->ldw, pl->Ka, pl->y.p, pl->P);
     }
     // ---- 1. prior, top-down
-    for (int m = 0; m < pl->n_levels; ++m) {
+    const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
+    if (fused) run_prior_fused(pl);
+    for (int m = 0; m < pl->n_levels && !fused; ++m) {
         LevelData& lv = pl->lev[m];
         const size_t nn = lv.nodes.size();
         if (!nn) continue;
@@ -611,6 +840,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
         {
             KTimer kt(pl, KF_PRIOR_TRSM, lv.fl_trsm);
+            if (!launch_trsm2(pl, lv.gTrsm2Prior.p, nn, lv.cwt, lv.max_tiles, 32))
             hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
                                lv.gTrsmPrior.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw, lv.c0,
                                (double*)nullptr);
@@ -633,7 +863,14 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         }
         {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
-            launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
+            const int ntl = pl->leaf_max_nop / 16;
+            if (ntl <= 12) {
+                launch_panel(pl, pl->gLeafCholC.p, nl);
+                const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
+                launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
+            } else {
+                launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
+            }
         }
         { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na); }
         if (pred) {
@@ -737,6 +974,21 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
     try {
         HIP_TRY(hipSetDevice(pl->device));
         HIP_TRY(hipMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
+        if (pl->regular) {
+            const int cw = pl->cw[0];
+            for (int m = 0; m < pl->NL; ++m) {
+                const LevelData& lv = pl->lev[m];
+                std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d, MRA_FAR_AWAY);
+                for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
+                    const int i = lv.nodes[sl];
+                    const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+                    for (long c = 0; c < rk; ++c)
+                        for (int k = 0; k < pl->d; ++k)
+                            kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
+                }
+                HIP_TRY(hipMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         pl->have_locs = true;
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
@@ -763,6 +1015,7 @@ int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
         if (kind < 0 || kind > MRA_KERNEL_IDEN || !params || n < 3) throw MraError(MRA_ERR_INVALID, "unknown kernel kind or too few parameters (need l, sig, scale)");
         if (!(params[0] > 0.0)) throw MraError(MRA_ERR_INVALID, "length scale must be positive");
         pl->kp.kind = kind; pl->kp.d = pl->d; pl->kp.l = params[0]; pl->kp.sig = params[1]; pl->kp.scale = params[2];
+        derive_kernel_params(pl->kp);
         pl->host_cov = false;
         pl->have_kernel = true;
         return MRA_OK;
@@ -836,6 +1089,7 @@ int mra_get_timers(mra_plan* pl, double* out, int cap) {
 int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (!pl) return MRA_ERR_INVALID;
     if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
+    if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }
 
@@ -857,6 +1111,26 @@ int mra_plan_info(mra_plan* pl, int64_t* out, int cap) {
     int n = std::min(cap, 8);
     for (int k = 0; k < n; ++k) out[k] = v[k];
     return n;
+}
+
+// Diagnostics: evaluate a device kernel on n distances (pyMRA/MRATools.py:265-301 on D = dist(...)).
+int mra_eval_kernel(int kind, const double* params, int n_params, const double* D, int64_t n, double* out) {
+    if (!params || n_params < 3 || !D || !out || n <= 0 || kind < 0 || kind > MRA_KERNEL_IDEN) return MRA_ERR_INVALID;
+    KernelParams kp{};
+    kp.kind = kind; kp.d = 1; kp.l = params[0]; kp.sig = params[1]; kp.scale = params[2];
+    derive_kernel_params(kp);
+    double *dD = nullptr, *dO = nullptr;
+    if (hipMalloc((void**)&dD, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&dO, n * sizeof(double)) != hipSuccess) {
+        g_last_error = "hipMalloc failed (no GPU?)";
+        if (dD) hipFree(dD);
+        return MRA_ERR_HIP;
+    }
+    hipMemcpy(dD, D, n * sizeof(double), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dD, dO, (long)n, kp);
+    hipError_t e = hipMemcpy(out, dO, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dD); hipFree(dO);
+    if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return MRA_ERR_HIP; }
+    return MRA_OK;
 }
 
 // ---- multi-GPU ------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4
 # every symbol include/mra_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "mra_device_count", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
-    "mra_plan_set_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
+    "mra_plan_set_kernel", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
     "mra_get_buffer", "mra_get_timers", "mra_plan_set_option", "mra_kernel_family_count",
     "mra_get_kernel_stats", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
@@ -68,6 +68,7 @@ def load_library():
         "mra_plan_set_obs": (C.c_int, [vp, vp, dbl]),
         "mra_plan_set_kernel": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "mra_plan_set_cov_block": (C.c_int, [vp, i32, vp, i64, i64, vp]),
+        "mra_eval_kernel": (C.c_int, [C.c_int, vp, C.c_int, vp, i64, vp]),
         "mra_run": (C.c_int, [vp, u32]),
         "mra_run_resume": (C.c_int, [vp]),
         "mra_get_likelihood": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl)]),
@@ -250,6 +251,18 @@ def comm_unique_id() -> bytes:
     if rc != 0:
         raise MraError(rc, (lib.mra_last_error(None) or b"").decode())
     return buf.raw
+
+
+def eval_kernel(kind, l, sig, scale, D):
+    """Device evaluation of a stationary kernel on an array of distances (tests)."""
+    lib = load_library()
+    D = np.ascontiguousarray(D, dtype=np.float64).ravel()
+    out = np.empty_like(D)
+    par = np.array([l, sig, scale], dtype=np.float64)
+    rc = lib.mra_eval_kernel(int(kind), _ptr(par), 3, _ptr(D), D.size, _ptr(out))
+    if rc != 0:
+        raise MraError(rc, (lib.mra_last_error(None) or b"").decode())
+    return out
 
 
 def device_count() -> int:

@@ -181,3 +181,21 @@ def test_api_errors(hip):
     assert tree.M == 3 and tree.J == 3 and tree.d == 1 and tree.r == 2
     assert abs(tree.getLikelihood()[0, 0] - float(cs["g"]["lik"])) < 1e-9
     assert np.array_equal(tree.obs_inds, np.where(np.isfinite(cs["y_obs"]))[0])
+
+
+def test_device_kernels_match_numpy_to_ulps(hip):
+    """ExpCovFun / Matern32 / Matern52 / Gaussian as the inference kernels evaluate them on the GPU vs
+    the NumPy formulas of pyMRA/MRATools.py:265-301 (row a1-a3 of SURVEY section 8)."""
+    import pymra_amd.MRATools as mt
+    rng = np.random.RandomState(1)
+    D = np.concatenate([[0.0], np.abs(rng.normal(size=20000)) * 0.7, 10.0 ** rng.uniform(-9, 2, size=20000)])
+    x = np.zeros((1, 1))
+    for kind, l, sig in ((mt.KIND_EXP, 0.3, 1.0), (mt.KIND_MATERN32, 0.3, 1.7), (mt.KIND_MATERN52, 2.0, 0.4),
+                         (mt.KIND_GAUSSIAN, 0.8, 1.2)):
+        spec = mt.KernelSpec(kind, l, sig, 1.5)
+        want = np.asarray(spec.evaluate(x, D.reshape(-1, 1))).ravel()
+        got = hip.eval_kernel(kind, l, sig, 1.5, D)
+        # exp(-t) carries the rounding of its argument: relative error ~ t * 2^-53, so compare where t <~ 30
+        big = want > 1e-13
+        assert np.max(np.abs(got[big] - want[big]) / want[big]) < 2e-14, kind
+        assert np.all(np.abs(got[~big] - want[~big]) <= 1e-11 * want[~big] + 1e-300)

@@ -26,6 +26,8 @@ for name in sys.argv[1:]:
     t0 = time.time()
     pl = HipPlan(topo, 0); pl.set_locs(locs); pl.set_obs(y_obs, c["R"]); pl.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
     pl.set_option(1, 1)
+    pl.set_option(2, int(os.environ.get('MRA_FUSED', '1')))
+    pl.run()   # warm-up (first-launch overheads)
     try:
         pl.run()
     except Exception as e:
