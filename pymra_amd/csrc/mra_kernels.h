@@ -141,6 +141,7 @@ struct GemmProb {
     long lda, ldb, ldc, ldcs;
     int M, N, K;
     int lower;              // 1: only 32x32 tiles with mt >= nt
+    int zc;                 // SUB: columns >= zc take C_in = 0 (0 = off)
 };
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s];
-            else if (EPI == EPI_SUB) v = *cp - acc[s];
+            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
             else if (EPI == EPI_COV) {
                 const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
                 v = (bcol < 0) ? 0.0 : cv;
@@ -405,6 +406,8 @@ struct Trsm2Prob {
     long ldL, ldx;
     int nt;               // column tiles
     int ntiles;           // 16-row tiles
+    int var_tile0;        // tiles >= var_tile0 update var[(t - var_tile0)*16 + r]
+    double var_sign;      // +1: var += |x|^2, -1: var -= |x|^2
 };
 
 __device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
@@ -462,10 +465,10 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
                 ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
             }
         }
-        if (pb.var) {
+        if (pb.var && t >= pb.var_tile0) {
             ssq += __shfl_xor(ssq, 16, 64);
             ssq += __shfl_xor(ssq, 32, 64);
-            if (q == 0) pb.var[(long)t * 16 + r] += ssq;
+            if (q == 0) pb.var[(long)(t - pb.var_tile0) * 16 + r] += pb.var_sign * ssq;
         }
     }
 }
@@ -507,6 +510,8 @@ struct CascadeArgs {
     long n_wg;
     int mlast;
     int knot_mode;
+    double* var_out;          // FULL: prior residual variance C(x,x) - |W[x]|^2 (nullptr: skip)
+    double cov0;
 };
 
 template <int CWT, int NLMAX, int DIM, int MODE>
@@ -630,13 +635,168 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
         }
     } else {
         double* o = ar.W + myrow * ar.ldw;
+        double ssq = 0.0;
 #pragma unroll
         for (int m = 0; m < NLMAX; ++m) {
             if (m <= ar.mlast) {
 #pragma unroll
-                for (int jb = 0; jb < CWT; ++jb) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = w[m][jb];
+                for (int jb = 0; jb < CWT; ++jb) {
+                    const d4 v = w[m][jb];
+                    *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+                    ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                }
             }
         }
+        if (ar.var_out) {
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Fused predictive cascade (regular trees), bottom-up over the non-leaf levels, one pass over W:
+//      X_m = W~^m[i] Lt_m^{-T};  var += |X_m|^2;  [W~^{<m} | ycol][i] -= X_m Zt_m^T      (MRANode.py:486-511)
+//  with all coarser tiles of the 16 rows in registers.  Inputs: W after the leaf update, var after the
+//  leaf part (prior residual variance minus |Tt|^2, may be slightly negative -> clamped here).
+//  Outputs: mean (= -ycol) and var only; W is not written back.
+// ------------------------------------------------------------------------------------------------
+struct PredLevel {
+    const double* F;      // [node][nf][nf] factorised fronts of this level (Lt, Zt in place)
+    const double* invF;   // [node][cwt][256]
+    int nf;
+};
+struct PredArgs {
+    PredLevel lev[8];
+    const double* W;
+    double* mean;
+    double* var;
+    long ldw;
+    int coff[8];
+    int ycol;                 // first column of the y block in W
+    const long* tile_row0;
+    const int* tile_chain;
+    const long* wg_tile0;
+    const int* wg_ntiles;
+    long n_wg;
+    int nl;                   // number of non-leaf levels
+};
+
+template <int CWT, int NLMAX>
+__global__ __launch_bounds__(512) void k_predict_cascade(PredArgs ar) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CW = CWT * 16;
+    constexpr int NTRI = CWT * (CWT - 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long t0 = ar.wg_tile0[blockIdx.x];
+    const int nt_wg = ar.wg_ntiles[blockIdx.x];
+    const bool active = wave < nt_wg;
+    const long t = t0 + (active ? wave : 0);
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    const long myrow = ar.tile_row0[t] + r;
+    const int* chain = ar.tile_chain + t0 * 8;
+    const double* wrow = ar.W + myrow * ar.ldw + 4 * q;
+    d4 w[NLMAX][CWT];
+#pragma unroll
+    for (int m = 0; m < NLMAX; ++m) {
+        if (m < ar.nl) {
+#pragma unroll
+            for (int jb = 0; jb < CWT; ++jb) w[m][jb] = *(const d4*)(wrow + ar.coff[m] + jb * 16);
+        }
+    }
+    d4 yt = *(const d4*)(wrow + ar.ycol);
+    double ssq = 0.0;
+#pragma unroll
+    for (int mm = 0; mm < NLMAX; ++mm) {
+        const int m = NLMAX - 1 - mm;
+        if (m < ar.nl) {
+            const PredLevel lv = ar.lev[m];
+            const int slot = chain[m];
+            const double* F = lv.F + (long)slot * lv.nf * lv.nf;
+            const double* inv = lv.invF + (long)slot * CWT * 256;
+            const int nzt = (m * CWT + 1) * CWT;            // Zt tiles: ancestors' tiles + the y tile, CWT k-tiles each
+            // ---- stage: Lt strictly-lower tiles, inverted diagonal blocks, Zt tiles [a][jb]
+            __syncthreads();
+            for (int e = threadIdx.x; e < (NTRI + CWT + nzt) * 128; e += blockDim.x) {
+                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
+                const double* src;
+                if (tile < NTRI) {
+                    int jb = 1;
+                    while ((jb + 1) * jb / 2 <= tile) ++jb;
+                    const int kb = tile - jb * (jb - 1) / 2;
+                    src = F + (long)(jb * 16 + row) * lv.nf + kb * 16 + c2;
+                } else if (tile < NTRI + CWT) {
+                    src = inv + (long)(tile - NTRI) * 256 + row * 16 + c2;
+                } else {
+                    const int zt = tile - NTRI - CWT, a = zt / CWT, jb = zt % CWT;
+                    src = F + (long)(CW + a * 16 + row) * lv.nf + jb * 16 + c2;
+                }
+                *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
+            }
+            __syncthreads();
+            if (active) {
+                d4 x[CWT];
+#pragma unroll
+                for (int jb = 0; jb < CWT; ++jb) {
+                    d4 acc = w[m][jb];
+                    d4 upd = zero;
+#pragma unroll
+                    for (int kb = 0; kb < CWT; ++kb) {
+                        if (kb < jb) {
+                            const d4 a = *(const d4*)(lds + (jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) upd = mfma16(a[j], x[kb][j], upd);
+                        }
+                    }
+                    acc -= upd;
+                    const d4 ia = *(const d4*)(lds + (NTRI + jb) * 256 + prow * 16 + 4 * q);
+                    d4 xx = zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], acc[j], xx);
+                    x[jb] = xx;
+                    ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
+                }
+                // ancestors' tiles: front row block a = (m-1-k)*CWT + kt  (W columns are deepest level first)
+#pragma unroll
+                for (int k = 0; k < NLMAX; ++k) {
+                    if (k < m) {
+#pragma unroll
+                        for (int kt = 0; kt < CWT; ++kt) {
+                            const int a = (m - 1 - k) * CWT + kt;
+                            d4 acc = zero;
+#pragma unroll
+                            for (int jb = 0; jb < CWT; ++jb) {
+                                const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc = mfma16(z[j], x[jb][j], acc);
+                            }
+                            w[k][kt] -= acc;
+                        }
+                    }
+                }
+                {
+                    const int a = m * CWT;                   // the y tile follows the ancestors
+                    d4 acc = zero;
+#pragma unroll
+                    for (int jb = 0; jb < CWT; ++jb) {
+                        const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = mfma16(z[j], x[jb][j], acc);
+                    }
+                    yt -= acc;
+                }
+            }
+        }
+    }
+    if (!active) return;
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (q == 0) {
+        const double v0 = ar.var[myrow];
+        ar.var[myrow] = (v0 > 0.0 ? v0 : 0.0) + ssq;
+        ar.mean[myrow] = -yt[0];
     }
 }
 

@@ -61,7 +61,7 @@ enum KFam {
 static const char* kfam_name[KF_COUNT] = {
     "k_gemm_nt<COV> prior resid", "k_panel_chol prior", "k_trsm_rows prior / fused prior cascade", "k_gemm_nt<COV> leaf resid",
     "k_panel_chol leaf", "k_gemm_nt<SET> leaf syrk", "k_gemm_nt<SUB> leaf update", "k_panel_chol front",
-    "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update", "small kernels"};
+    "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update / fused predict cascade", "small kernels"};
 
 template <class T>
 struct DevVec {
@@ -322,8 +322,8 @@ static void build_static(mra_plan* pl) {
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
             tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
             lv.fl_trsm += (double)nr * lv.cw * lv.cw;
-            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16)};
-            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16)};
+            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0};
+            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
             fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
@@ -508,8 +508,8 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
         pk[t] = PanelProb{Pn, inv, nop, (nop + na) / 16, nop / 16, i};
         pc[t] = PanelProb{Pn, inv, nop, nop / 16, nop / 16, i};
-        tf[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, (int)((na + nr) / 16)};
-        tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16};
+        tf[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, pl->var.p + r0, nop, nop, nop / 16, (int)((na + nr) / 16), na / 16, -1.0};
+        tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16, 0, 1.0};
         pl->leaf_max_tiles_full = std::max(pl->leaf_max_tiles_full, (int)((na + nr) / 16));
         pl->leaf_max_tiles_lik = std::max(pl->leaf_max_tiles_lik, na / 16);
         pl->fl_leaf_chol += (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop;
@@ -522,6 +522,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         GemmProb u{};
         u.A = Pn + (size_t)(nop + na) * nop; u.lda = nop; u.B = Pn + (size_t)nop * nop; u.ldb = nop;
         u.C = pl->W.p + r0 * pl->ldw + a0; u.ldc = pl->ldw; u.M = (int)nr; u.N = na; u.K = nop; u.lower = 0;
+        u.zc = na - MRA_YB;                  // y block: C_in = 0 (the column still holds y itself)
         gu[t] = u;
         pl->fl_leaf_update += 2.0 * nr * na * nop;
     }
@@ -633,6 +634,8 @@ static void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) {
 
 // whole prior of a regular tree: per level a tiny knot pass (knot rows cascade -> kInv -> Cholesky),
 // then ONE cascade over all leaf row tiles that writes W once
+static double kernel_cov0(const mra_plan* pl) { return pl->kp.amp; }   // C(x,x) of every stationary kernel: amp * 1
+
 static void run_prior_fused(mra_plan* pl) {
     const int cw = pl->cw[0];
     CascadeArgs base{};
@@ -668,10 +671,38 @@ static void run_prior_fused(mra_plan* pl) {
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.n_wg = pl->n_fwg;
+        ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
         ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
         ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p;
         launch_cascade_any(pl, ar);
     }
+}
+
+template <int CWT, int NLMAX>
+static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX>), dim3((unsigned)ar.n_wg), dim3(64 * pl->cascade_wpw), lds, pl->stream, ar);
+}
+
+static void run_predict_fused(mra_plan* pl) {
+    PredArgs ar{};
+    for (int m = 0; m < pl->NL; ++m) {
+        ar.lev[m].F = pl->lev[m].F.p; ar.lev[m].invF = pl->lev[m].invF.p; ar.lev[m].nf = pl->lev[m].nf;
+        ar.coff[m] = pl->coff[m];
+    }
+    ar.W = pl->W.p; ar.mean = pl->mean.p; ar.var = pl->var.p; ar.ldw = pl->ldw; ar.ycol = pl->Ka;
+    ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p; ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
+    ar.n_wg = pl->n_fwg; ar.nl = pl->NL;
+    const int cwt = pl->CWT, mmax = pl->NL - 1;
+    const size_t lds = (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax * cwt + 1) * cwt) * 2048;
+    double fl = 0;
+    for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
+    KTimer kt(pl, KF_PRED_UPDATE, fl);
+    if (ar.n_wg <= 0) return;
+    if (cwt == 1) launch_predict_cascade<1, 8>(pl, ar, lds);
+    else if (cwt == 2) launch_predict_cascade<2, 8>(pl, ar, lds);
+    else launch_predict_cascade<4, 4>(pl, ar, lds);
 }
 
 static void phase_mark(mra_plan* pl, int k) { hipEventRecord(pl->ev[k], pl->stream); }
@@ -733,7 +764,9 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
         run_front_level(pl, m);
     }
     phase_mark(pl, 3);
-    if (pl->run_flags & MRA_RUN_PREDICT) {
+    const bool fusedp = pl->regular && pl->use_fused && !pl->host_cov;
+    if ((pl->run_flags & MRA_RUN_PREDICT) && fusedp) run_predict_fused(pl);
+    if ((pl->run_flags & MRA_RUN_PREDICT) && !fusedp) {
         for (int m = pl->n_levels - 1; m >= 0; --m) {
             LevelData& lv = pl->lev[m];
             const size_t nn = lv.nodes.size();
@@ -757,7 +790,7 @@ static void finish_run(mra_plan* pl) {
         KTimer kt(pl, KF_MISC, 0);
         const int nsum = pl->reduce_level >= 0 ? (int)pl->level_ptr[pl->reduce_level + 1] : pl->n_nodes;
         hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->scal.p);
-        if (pl->run_flags & MRA_RUN_PREDICT)
+        if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov))
             hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
                                pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
     }
@@ -874,7 +907,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         }
         { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na); }
         if (pred) {
-            {
+            if (!fused || pl->leaf_max_nop / 16 > 12) {
                 KTimer kt(pl, KF_MISC, 0);
                 double cov0 = 0.0;
                 if (!pl->host_cov) {
