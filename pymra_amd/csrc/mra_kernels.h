@@ -142,6 +142,11 @@ struct GemmProb {
     int M, N, K;
     int lower;              // 1: only 32x32 tiles with mt >= nt
     int zc;                 // SUB: columns >= zc take C_in = 0 (0 = off)
+    // COV, leaves: rows that are observed are also copied (plus diag_add on the diagonal) into the
+    // square block C2 (ldc): C2[rowmap[row]][col]
+    const int* rowmap;
+    double* C2;
+    double diag_add;
 };
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
@@ -203,6 +208,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             else if (EPI == EPI_COV) {
                 const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
                 v = (bcol < 0) ? 0.0 : cv;
+                if (pb.rowmap) {
+                    const int op = pb.rowmap[row];
+                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                }
             } else {
                 v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
             }
@@ -408,6 +417,12 @@ struct Trsm2Prob {
     int ntiles;           // 16-row tiles
     int var_tile0;        // tiles >= var_tile0 update var[(t - var_tile0)*16 + r]
     double var_sign;      // +1: var += |x|^2, -1: var -= |x|^2
+    // the first gtiles row tiles take their right-hand side from a transposed gather:
+    // R[a][k] = gW[gidx[k] * gld + a]  (0 where gidx[k] < 0): the leaf's Ut = [W_anc[o] | y_o]^T
+    const int* gidx;
+    const double* gW;
+    long gld;
+    int gtiles;
 };
 
 __device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
@@ -447,7 +462,16 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
 #pragma unroll
         for (int jb = 0; jb < NTMAX; ++jb) {
             if (jb < nt) {
-                d4 acc = *(const d4*)(xp + jb * 16);
+                d4 acc;
+                if (t < pb.gtiles) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int gi = pb.gidx[jb * 16 + 4 * q + j];
+                        acc[j] = gi < 0 ? 0.0 : pb.gW[(long)gi * pb.gld + t * 16 + r];
+                    }
+                } else {
+                    acc = *(const d4*)(xp + jb * 16);
+                }
                 d4 upd = zero;
 #pragma unroll
                 for (int kb = 0; kb < jb; ++kb) {
@@ -512,6 +536,15 @@ struct CascadeArgs {
     int knot_mode;
     double* var_out;          // FULL: prior residual variance C(x,x) - |W[x]|^2 (nullptr: skip)
     double cov0;
+    // FULL: observed rows also scatter their whitened basis (transposed) and y into the leaf panel's
+    // Ut block: Ut[a][k] = W[row][a], Ut[ycol][k] = y[row] with k = obs_pos[row]  (nullptr: skip)
+    const int* obs_pos;       // [P] position of a row among its leaf's observations, -1 if unobserved
+    const int* tile_leaf;     // [ntiles] leaf number of each tile
+    double* const* leaf_ut;   // [leaf] pointer to the Ut block (row-major, ld = nop)
+    const int* leaf_nop;      // [leaf]
+    const double* y;          // [P]
+    int ut_off[8];            // Ut row of level m's first column = ut_off[m]
+    int ut_yrow;              // Ut row of y
 };
 
 template <int CWT, int NLMAX, int DIM, int MODE>
@@ -651,6 +684,26 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             ssq += __shfl_xor(ssq, 16, 64);
             ssq += __shfl_xor(ssq, 32, 64);
             if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
+        }
+        if (ar.obs_pos) {
+            const int op = ar.obs_pos[myrow];
+            if (op >= 0) {
+                const int lf = ar.tile_leaf[t];
+                double* ut = ar.leaf_ut[lf];
+                const long nop = ar.leaf_nop[lf];
+#pragma unroll
+                for (int m = 0; m < NLMAX; ++m) {
+                    if (m <= ar.mlast) {
+#pragma unroll
+                        for (int jb = 0; jb < CWT; ++jb) {
+                            const d4 v = w[m][jb];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
+                        }
+                    }
+                }
+                if (q == 0) ut[(long)ar.ut_yrow * nop + op] = ar.y[myrow];
+            }
         }
     }
 }
@@ -876,6 +929,17 @@ __global__ void k_leaf_fill(const LeafProb* __restrict__ probs, const double* __
             v = (ok >= 0) ? W[(long)ok * ldw + pb.a0 + t] : 0.0;
         }
         pb.Pn[(long)row * pb.ld + k] = v;
+    }
+}
+
+// phantom observation rows of a leaf's C block: identity (the real rows come from the COV epilogue)
+__global__ void k_leaf_cphantom(const LeafProb* __restrict__ probs, const int* __restrict__ n_obs) {
+    const LeafProb pb = probs[blockIdx.x];
+    const int no = n_obs[blockIdx.x];
+    const int total = (pb.nop - no) * pb.nop;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int row = no + e / pb.nop, col = e % pb.nop;
+        pb.Pn[(long)row * pb.ld + col] = (row == col) ? 1.0 : 0.0;
     }
 }
 

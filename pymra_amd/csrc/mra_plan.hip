@@ -144,11 +144,12 @@ struct mra_plan {
     std::vector<int> leaf_nop;
     std::vector<long> leaf_poff, leaf_goff, leaf_ioff;
     DevVec<double> panel, leafInv, Gt;
-    DevVec<int> obs_idx;
+    DevVec<int> obs_idx, obs_pos, leaf_nobs, leaf_nop_dev, ft_leaf;
+    DevVec<double*> leaf_ut;
     DevVec<LeafProb> gLeaf;
     DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
-    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik;
+    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
     int leaf_max_tiles_full = 0, leaf_max_tiles_lik = 0;
     DevVec<AsmChild> asmKids;
     long leaf_max_rows = 0;
@@ -160,6 +161,7 @@ struct mra_plan {
     struct FusedLevel {
         DevVec<double> kx, Wk;
         DevVec<int> kvalid, kt_rows, kt_chain, kt_knot0, kt_wgn;
+        DevVec<GemmProb> gKinv;
         DevVec<long> kt_wg0;
         long n_ktiles = 0, n_kwg = 0;
     };
@@ -322,8 +324,8 @@ static void build_static(mra_plan* pl) {
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
             tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
             lv.fl_trsm += (double)nr * lv.cw * lv.cw;
-            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0};
-            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0};
+            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
+            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
             fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
@@ -422,9 +424,22 @@ static void build_static(mra_plan* pl) {
             f.kvalid.upload(kv); f.kt_rows.upload(rows); f.kt_chain.upload(chain); f.kt_knot0.upload(knot0);
             f.n_ktiles = (long)knot0.size();
             f.kt_wg0.upload(wg0); f.kt_wgn.upload(wgn); f.n_kwg = (long)wg0.size();
+            {
+                // kInv of every node of the level: kernel(knots, knots) - Wk Wk^T as one batched COV product
+                std::vector<GemmProb> gk(nn);
+                for (size_t sl = 0; sl < nn; ++sl) {
+                    GemmProb g{};
+                    g.A = f.Wk.p + sl * (size_t)cw * (m * cw); g.lda = m * cw; g.B = g.A; g.ldb = m * cw;
+                    g.C = pl->lev[m].Lp.p + sl * (size_t)cw * cw; g.ldc = cw;
+                    g.XA = f.kx.p + sl * (size_t)cw * pl->d; g.XB = g.XA;
+                    g.M = cw; g.N = cw; g.K = m * cw; g.lower = 0;
+                    gk[sl] = g;
+                }
+                f.gKinv.upload(gk);
+            }
         }
         std::vector<long> r0s, fwg0;
-        std::vector<int> chains, fwgn;
+        std::vector<int> chains, fwgn, tleaf;
         for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
             const int i = pl->leaf_nodes[t];
             int ch[8];
@@ -435,10 +450,11 @@ static void build_static(mra_plan* pl) {
                     fwgn.push_back((int)std::min<long>(pl->cascade_wpw, (pl->row1[i] - p) / 16));
                 }
                 r0s.push_back(p);
+                tleaf.push_back((int)t);
                 for (int k = 0; k < 8; ++k) chains.push_back(ch[k]);
             }
         }
-        pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains);
+        pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains); pl->ft_leaf.upload(tleaf);
         pl->n_ftiles = (long)r0s.size();
         pl->ft_wg0.upload(fwg0); pl->ft_wgn.upload(fwgn); pl->n_fwg = (long)fwg0.size();
         {
@@ -454,7 +470,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->leaf_nop.assign(nl, 0);
     pl->leaf_poff.assign(nl + 1, 0);
     pl->leaf_ioff.assign(nl + 1, 0);
-    std::vector<int> obs;
+    std::vector<int> obs, opos(pl->P, -1), nobs(nl, 0);
     std::vector<long> obs_off(nl + 1, 0);
     pl->leaf_max_rows = 0; pl->leaf_max_nop = 0; pl->leaf_max_na = 0; pl->leaf_max_ht = 0;
     for (size_t t = 0; t < nl; ++t) {
@@ -463,10 +479,11 @@ static void build_leaf(mra_plan* pl, const double* y) {
         int no = 0;
         obs_off[t] = (long)obs.size();
         for (long p = pl->row0[i]; p < pl->row1[i]; ++p)
-            if (std::isfinite(y[p])) { obs.push_back((int)p); ++no; }
+            if (std::isfinite(y[p])) { obs.push_back((int)p); opos[p] = no; ++no; }
         const int nop = (no + 15) / 16 * 16;
         for (int k = no; k < nop; ++k) obs.push_back(-1);
         pl->leaf_nop[t] = nop;
+        nobs[t] = no;
         const long nr = pl->row1[i] - pl->row0[i];
         pl->leaf_poff[t + 1] = pl->leaf_poff[t] + (long)(nop + na + nr) * nop;
         pl->leaf_ioff[t + 1] = pl->leaf_ioff[t] + (long)(nop / 16) * 256;
@@ -476,7 +493,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->leaf_max_ht = std::max(pl->leaf_max_ht, (int)((nop + na + nr) / 16));
     }
     obs_off[nl] = (long)obs.size();
-    pl->obs_idx.upload(obs);
+    pl->obs_idx.upload(obs); pl->obs_pos.upload(opos); pl->leaf_nobs.upload(nobs);
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
     std::vector<LeafProb> lp(nl);
@@ -502,14 +519,15 @@ static void build_leaf(mra_plan* pl, const double* y) {
         g.C = Pn + (size_t)(nop + na) * nop; g.ldc = nop;
         g.XA = pl->X.p + r0 * pl->d; g.XB = pl->X.p;
         g.M = (int)nr; g.N = nop; g.K = Kanc; g.lower = 0;
+        g.rowmap = pl->obs_pos.p + r0; g.C2 = Pn; g.diag_add = pl->R;
         gr[t] = g;
         pl->fl_leaf_resid += 2.0 * nr * nop * Kanc;
         double* inv = pl->leafInv.p + pl->leaf_ioff[t];
         pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
         pk[t] = PanelProb{Pn, inv, nop, (nop + na) / 16, nop / 16, i};
         pc[t] = PanelProb{Pn, inv, nop, nop / 16, nop / 16, i};
-        tf[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, pl->var.p + r0, nop, nop, nop / 16, (int)((na + nr) / 16), na / 16, -1.0};
-        tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16, 0, 1.0};
+        tf[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, pl->var.p + r0, nop, nop, nop / 16, (int)((na + nr) / 16), na / 16, -1.0, q.obs, pl->W.p + a0, pl->ldw, na / 16};
+        tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16, 0, 1.0, q.obs, pl->W.p + a0, pl->ldw, na / 16};
         pl->leaf_max_tiles_full = std::max(pl->leaf_max_tiles_full, (int)((na + nr) / 16));
         pl->leaf_max_tiles_lik = std::max(pl->leaf_max_tiles_lik, na / 16);
         pl->fl_leaf_chol += (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop;
@@ -526,9 +544,20 @@ static void build_leaf(mra_plan* pl, const double* y) {
         gu[t] = u;
         pl->fl_leaf_update += 2.0 * nr * na * nop;
     }
+    {
+        std::vector<double*> uts(nl);
+        for (size_t t = 0; t < nl; ++t) uts[t] = pl->panel.p + pl->leaf_poff[t] + (size_t)pl->leaf_nop[t] * pl->leaf_nop[t];
+        pl->leaf_ut.upload(uts);
+        pl->leaf_nop_dev.upload(pl->leaf_nop);
+        // the Ut blocks start from zero: rows of the y block beyond y itself and phantom observation columns stay zero
+        if (pl->panel.n) HIP_TRY(hipMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
+    }
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
+    for (auto& e : tf) e.gtiles = 0;
+    for (auto& e : tk) e.gtiles = 0;
+    pl->gLeafTrsmFullPlain.upload(tf); pl->gLeafTrsmLikPlain.upload(tk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,12 +686,7 @@ static void run_prior_fused(mra_plan* pl) {
             ar.Wk_out = pl->fl[m].Wk.p;
             launch_cascade_any(pl, ar);
         }
-        {
-            KTimer kt(pl, KF_MISC, 0);
-            dim3 grid((unsigned)((cw * cw + 255) / 256), (unsigned)nn);
-            if (pl->d == 1) hipLaunchKernelGGL((k_knot_kinv<1>), grid, dim3(256), 0, pl->stream, pl->fl[m].kx.p, pl->fl[m].kvalid.p, pl->fl[m].Wk.p, lv.Lp.p, cw, m * cw, pl->kp);
-            else hipLaunchKernelGGL((k_knot_kinv<2>), grid, dim3(256), 0, pl->stream, pl->fl[m].kx.p, pl->fl[m].kvalid.p, pl->fl[m].Wk.p, lv.Lp.p, cw, m * cw, pl->kp);
-        }
+        { KTimer kt(pl, KF_MISC, 0); launch_gemm<EPI_COV>(pl, pl->fl[m].gKinv.p, nn, cw, cw); }
         { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
     }
     {
@@ -672,6 +696,13 @@ static void run_prior_fused(mra_plan* pl) {
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.n_wg = pl->n_fwg;
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
+        if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
+            ar.obs_pos = pl->obs_pos.p; ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p;
+            ar.y = pl->y.p;
+            // Ut rows follow W's ancestor columns of a last-level leaf: a = column - asuf[NL]
+            for (int m = 0; m < pl->NL; ++m) ar.ut_off[m] = pl->coff[m] - pl->asuf[pl->NL];
+            ar.ut_yrow = pl->Ka - pl->asuf[pl->NL];
+        }
         ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
         ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p;
         launch_cascade_any(pl, ar);
@@ -890,9 +921,14 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         }
         if (pl->leaf_max_nop > 0) {
             KTimer kt(pl, KF_MISC, 0);
-            const long total = (long)(pl->leaf_max_nop + pl->leaf_max_na) * pl->leaf_max_nop;
-            dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nl);
-            hipLaunchKernelGGL(k_leaf_fill, grid, dim3(256), 0, pl->stream, pl->gLeaf.p, pl->W.p, (long)pl->ldw, pl->R);
+            if (pl->leaf_max_nop / 16 <= 12) {
+                // C comes from the COV epilogue, Ut from the gather inside k_trsm_rows2: only the phantom rows remain
+                hipLaunchKernelGGL(k_leaf_cphantom, dim3((unsigned)nl), dim3(256), 0, pl->stream, pl->gLeaf.p, pl->leaf_nobs.p);
+            } else {
+                const long total = (long)(pl->leaf_max_nop + pl->leaf_max_na) * pl->leaf_max_nop;
+                dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nl);
+                hipLaunchKernelGGL(k_leaf_fill, grid, dim3(256), 0, pl->stream, pl->gLeaf.p, pl->W.p, (long)pl->ldw, pl->R);
+            }
         }
         {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
@@ -900,7 +936,8 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             if (ntl <= 12) {
                 launch_panel(pl, pl->gLeafCholC.p, nl);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
-                launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
+                if (fused) launch_trsm2(pl, pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p, nl, ntl, mt, mt);
+                else launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
             } else {
                 launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
             }
@@ -1011,7 +1048,9 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
             const int cw = pl->cw[0];
             for (int m = 0; m < pl->NL; ++m) {
                 const LevelData& lv = pl->lev[m];
-                std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d, MRA_FAR_AWAY);
+                std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d);
+                for (size_t e = 0; e < kx.size(); ++e)           // phantom knots: far away and far from each other
+                    kx[e] = MRA_FAR_AWAY * (double)(2 + (e / pl->d) % cw);
                 for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
                     const int i = lv.nodes[sl];
                     const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
