@@ -132,6 +132,7 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
  * (0 .. mra_kernel_family_count()-1), its name, the number of launches, their summed device
  * milliseconds and the algorithmic flop count of those launches. */
 #define MRA_OPT_KERNEL_TIMING  1
+#define MRA_OPT_GEMM_LDS       3   /* 1 (default): LDS-tiled batched GEMM; 0: direct-load variant */
 #define MRA_OPT_FUSED          2   /* 1 (default): fused cascade kernels on regular trees; 0: level-by-level kernels */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 int mra_kernel_family_count(void);

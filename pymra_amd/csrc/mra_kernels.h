@@ -27,6 +27,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define MRA_YB 16
 
+// row permutation of the "vec" tile layout (see k_trsm_rows2)
+__device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
+
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
@@ -147,7 +150,12 @@ struct GemmProb {
     const int* rowmap;
     double* C2;
     double diag_add;
+    // K split into segments (sum over a node's children): when nseg > 0, A/B/lda/ldb/K are ignored
+    const struct GemmSeg* segs;
+    int nseg;
+    int diag_one;           // SET: add 1 on the diagonal for row == col < diag_one (front identity block)
 };
+struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; };
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
 
@@ -163,30 +171,36 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
     const int m0 = mt << 5, n0 = nt << 5;
     const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
 
-    const double* a0p = pb.A + (long)(m0 + r) * pb.lda + 4 * q;
-    const double* a1p = a0p + 16 * pb.lda;
     int br0 = n0 + r, br1 = n0 + 16 + r;
     if (pb.idxB) {
         br0 = pb.idxB[n0 + r];
         br1 = nv1 ? pb.idxB[n0 + 16 + r] : -1;
     }
     const bool bz0 = br0 < 0, bz1 = (!nv1) || br1 < 0;
-    const double* b0p = pb.B + (long)(bz0 ? 0 : br0) * pb.ldb + 4 * q;
-    const double* b1p = pb.B + (long)(bz1 ? 0 : br1) * pb.ldb + 4 * q;
-
     d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
     const d4 zero = {0, 0, 0, 0};
-    for (int k0 = 0; k0 < pb.K; k0 += 16) {
-        d4 a0 = *(const d4*)(a0p + k0);
-        d4 a1 = mv1 ? *(const d4*)(a1p + k0) : zero;
-        d4 b0 = bz0 ? zero : *(const d4*)(b0p + k0);
-        d4 b1 = bz1 ? zero : *(const d4*)(b1p + k0);
+    const int nseg = pb.nseg > 0 ? pb.nseg : 1;
+    for (int sg = 0; sg < nseg; ++sg) {
+        const double *Ap = pb.A, *Bp = pb.B;
+        long lda = pb.lda, ldb = pb.ldb;
+        int K = pb.K;
+        if (pb.nseg > 0) { const GemmSeg g = pb.segs[sg]; Ap = g.A; Bp = g.B; lda = g.lda; ldb = g.ldb; K = g.K; }
+        const double* a0p = Ap + (long)(m0 + r) * lda + 4 * q;
+        const double* a1p = a0p + 16 * lda;
+        const double* b0p = Bp + (long)(bz0 ? 0 : br0) * ldb + 4 * q;
+        const double* b1p = Bp + (long)(bz1 ? 0 : br1) * ldb + 4 * q;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            d4 a0 = *(const d4*)(a0p + k0);
+            d4 a1 = mv1 ? *(const d4*)(a1p + k0) : zero;
+            d4 b0 = bz0 ? zero : *(const d4*)(b0p + k0);
+            d4 b1 = bz1 ? zero : *(const d4*)(b1p + k0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            c00 = mfma16(a0[j], b0[j], c00);
-            c01 = mfma16(a0[j], b1[j], c01);
-            c10 = mfma16(a1[j], b0[j], c10);
-            c11 = mfma16(a1[j], b1[j], c11);
+            for (int j = 0; j < 4; ++j) {
+                c00 = mfma16(a0[j], b0[j], c00);
+                c01 = mfma16(a0[j], b1[j], c01);
+                c10 = mfma16(a1[j], b0[j], c10);
+                c11 = mfma16(a1[j], b1[j], c11);
+            }
         }
     }
     // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             const int row = mb + q + 4 * s;
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
-            if (EPI == EPI_SET) v = acc[s];
+            if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
             else if (EPI == EPI_COV) {
                 const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
@@ -219,6 +233,110 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         }
     };
     const int bc0 = pb.idxB ? br0 : n0 + r, bc1 = pb.idxB ? br1 : n0 + 16 + r;
+    emit(c00, m0, n0, bc0);
+    if (nv1) emit(c01, m0, n0 + 16, bc1);
+    if (mv1) emit(c10, m0 + 16, n0, bc0);
+    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  LDS-tiled variant of k_gemm_nt: 64x64 output tile per workgroup (4 waves, 32x32 each), K stepped
+//  by 16 through a double-buffered LDS stage (one barrier per step, global loads of step k+1 in
+//  flight while step k is on the MFMA pipe).  Halves the L1/L2 operand traffic per MFMA of the
+//  direct-load kernel above; same GemmProb, same epilogues.
+// ------------------------------------------------------------------------------------------------
+#define GL_LDS_LD 18      /* doubles per staged row: 16 + 2 pad -> conflict-free 32-byte fragment reads */
+
+template <int EPI, int DIM, int MODE>
+__global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp) {
+    __shared__ __attribute__((aligned(16))) double sA[2][64 * GL_LDS_LD];
+    __shared__ __attribute__((aligned(16))) double sB[2][64 * GL_LDS_LD];
+    const GemmProb pb = probs[blockIdx.y];
+    const int tn = (pb.N + 63) >> 6, tm = (pb.M + 63) >> 6;
+    if ((int)blockIdx.x >= tm * tn) return;
+    const int mt = blockIdx.x / tn, nt = blockIdx.x % tn;
+    if (pb.lower && nt > mt) return;
+    const int M0 = mt << 6, N0 = nt << 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves
+    // ---- staging role: thread -> (row, 32-byte chunk) of A and of B
+    const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
+    const bool a_ok = (M0 + srow) < pb.M;
+    const double* ap = pb.A + (long)(M0 + (a_ok ? srow : 0)) * pb.lda + sch;
+    long brow = N0 + srow;
+    bool b_ok = brow < pb.N;
+    if (b_ok && pb.idxB) { const int ib = pb.idxB[brow]; b_ok = ib >= 0; brow = b_ok ? ib : 0; }
+    const double* bp = pb.B + (b_ok ? brow : 0) * pb.ldb + sch;
+    const d4 zero = {0, 0, 0, 0};
+    d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
+    const int nk = pb.K >> 4;
+    d4 ra = zero, rb = zero;
+    if (nk > 0) {
+        ra = a_ok ? *(const d4*)ap : zero;
+        rb = b_ok ? *(const d4*)bp : zero;
+        *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra;
+        *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb;
+    }
+    __syncthreads();
+    const int arow0 = (wm * 32 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
+    const int brow0 = (wn * 32 + r) * GL_LDS_LD + 4 * q, brow1 = brow0 + 16 * GL_LDS_LD;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) {
+            ra = a_ok ? *(const d4*)(ap + (ks + 1) * 16) : zero;
+            rb = b_ok ? *(const d4*)(bp + (ks + 1) * 16) : zero;
+        }
+        const d4 a0 = *(const d4*)(&sA[cur][arow0]);
+        const d4 a1 = *(const d4*)(&sA[cur][arow1]);
+        const d4 b0 = *(const d4*)(&sB[cur][brow0]);
+        const d4 b1 = *(const d4*)(&sB[cur][brow1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c00 = mfma16(a0[j], b0[j], c00);
+            c01 = mfma16(a0[j], b1[j], c01);
+            c10 = mfma16(a1[j], b0[j], c10);
+            c11 = mfma16(a1[j], b1[j], c11);
+        }
+        if (ks + 1 < nk) {
+            *(d4*)(&sA[cur ^ 1][srow * GL_LDS_LD + sch]) = ra;
+            *(d4*)(&sB[cur ^ 1][srow * GL_LDS_LD + sch]) = rb;
+        }
+        __syncthreads();
+    }
+    // ---- epilogue (as k_gemm_nt): accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
+    const int m0 = M0 + wm * 32, n0 = N0 + wn * 32;
+    if (m0 >= pb.M || n0 >= pb.N) return;
+    const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
+    int bc0 = n0 + r, bc1 = n0 + 16 + r;
+    if (pb.idxB) { bc0 = pb.idxB[n0 + r]; bc1 = nv1 ? pb.idxB[n0 + 16 + r] : -1; }
+    auto emit = [&](d4 acc, int mb, int nb, int bcol) {
+        const int col = nb + r;
+        double xb[DIM];
+        if (EPI == EPI_COV) {
+            const long bc = bcol < 0 ? 0 : bcol;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xb[c] = pb.XB[bc * DIM + c];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = mb + q + 4 * s;
+            double* cp = pb.C + (long)row * pb.ldc + col;
+            double v;
+            if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
+            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
+            else if (EPI == EPI_COV) {
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
+                v = (bcol < 0) ? 0.0 : cv;
+                if (pb.rowmap) {
+                    const int op = pb.rowmap[row];
+                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                }
+            } else {
+                v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+            }
+            *cp = v;
+        }
+    };
     emit(c00, m0, n0, bc0);
     if (nv1) emit(c01, m0, n0 + 16, bc1);
     if (mv1) emit(c10, m0 + 16, n0, bc0);
@@ -351,6 +469,84 @@ __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+//  Cholesky of many small matrices (the leaves' C blocks): ONE WAVE per matrix, no workgroup barriers,
+//  so the serial 16x16 diagonal-block factorisations of different matrices overlap on a CU instead of
+//  idling three of four waves (k_panel_chol).  Left-looking over 16x16 tiles in vec layout; the
+//  matrix stays in global memory (L1/L2-hot, written and re-read by the same wave).
+// ------------------------------------------------------------------------------------------------
+template <int NTMAX>
+__global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
+                                                    double* __restrict__ dnode, int* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16];
+    __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int ip = blockIdx.x * 4 + wave;
+    if (ip >= nprob) return;
+    const PanelProb pb = probs[ip];
+    const int nt = pb.ne;
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    double logacc = 0.0;
+    double* sd = sdiag[wave];
+    double* si = sinv[wave];
+#pragma unroll 1
+    for (int jb = 0; jb < nt; ++jb) {
+        // ---- diagonal tile: left-looking update, then factor + invert
+        {
+            double* tp = pb.P + (long)(jb * 16 + r) * pb.ld + jb * 16 + 4 * q;
+            d4 acc = *(const d4*)tp;
+            d4 upd = zero;
+            for (int kb = 0; kb < jb; ++kb) {
+                const d4 a = *(const d4*)(pb.P + (long)(jb * 16 + prow) * pb.ld + kb * 16 + 4 * q);
+                const d4 b = *(const d4*)(pb.P + (long)(jb * 16 + r) * pb.ld + kb * 16 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
+            }
+            acc -= upd;
+            *(d4*)(sd + r * 16 + 4 * q) = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            double a[16], m[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? sd[r * 16 + k] : 0.0;
+            bool bad = false;
+            logacc += chol16_inv(a, m, r, bad);
+            if (lane < 16) {
+                double* dp = pb.P + (long)(jb * 16 + lane) * pb.ld + jb * 16;
+                double* ip2 = pb.invd + (long)jb * 256;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) dp[k] = a[k];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { si[i * 16 + lane] = m[i]; ip2[i * 16 + lane] = m[i]; }
+                if (bad && lane == 0) atomicMax(err, pb.node + 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const d4 ia = *(const d4*)(si + prow * 16 + 4 * q);
+        // ---- rows below
+        for (int ib = jb + 1; ib < nt; ++ib) {
+            double* tp = pb.P + (long)(ib * 16 + r) * pb.ld + jb * 16 + 4 * q;
+            d4 acc = *(const d4*)tp;
+            d4 upd = zero;
+            for (int kb = 0; kb < jb; ++kb) {
+                const d4 a = *(const d4*)(pb.P + (long)(jb * 16 + prow) * pb.ld + kb * 16 + 4 * q);
+                const d4 b = *(const d4*)(pb.P + (long)(ib * 16 + r) * pb.ld + kb * 16 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
+            }
+            acc -= upd;
+            d4 x = zero;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x = mfma16(ia[j], acc[j], x);
+            *(d4*)tp = x;
+        }
+        __threadfence_block();          // this wave's stores before its own later loads (other lanes)
+    }
+    if (lane == 0) dnode[pb.node] = 2.0 * logacc;
+}
+
+// ------------------------------------------------------------------------------------------------
 //  X = R L^{-T} on 16-row tiles (in place), optional var += rowsumsq(X)
 // ------------------------------------------------------------------------------------------------
 struct TrsmNode {
@@ -425,7 +621,6 @@ struct Trsm2Prob {
     int gtiles;
 };
 
-__device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
 
 template <int NTMAX>
 __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict__ probs, int tiles_per_wg) {

@@ -150,13 +150,16 @@ struct mra_plan {
     DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
+    DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
+    DevVec<GemmSeg> parentSegs;
+    bool parent_syrk = false, direct_parent = false;
     int leaf_max_tiles_full = 0, leaf_max_tiles_lik = 0;
     DevVec<AsmChild> asmKids;
     long leaf_max_rows = 0;
     int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
     // fused ("regular tree") path
-    bool regular = false, use_fused = true;
+    bool regular = false, use_fused = true, gemm_lds = true;
     int NL = 0, CWT = 0;
     struct FusedLevel {
         DevVec<double> kx, Wk;
@@ -552,6 +555,33 @@ static void build_leaf(mra_plan* pl, const double* y) {
         // the Ut blocks start from zero: rows of the y block beyond y itself and phantom observation columns stay zero
         if (pl->panel.n) HIP_TRY(hipMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
     }
+    pl->parent_syrk = false;
+    if (pl->regular && pl->NL >= 1) {
+        const LevelData& lv = pl->lev[pl->NL - 1];
+        std::vector<GemmProb> ps(lv.nodes.size());
+        std::vector<GemmSeg> segs;
+        std::vector<std::pair<size_t, int>> where(lv.nodes.size());
+        for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx) {
+            const int i = lv.nodes[sidx];
+            where[sidx] = {segs.size(), pl->child_ptr[i + 1] - pl->child_ptr[i]};
+            for (int c = pl->child_ptr[i]; c < pl->child_ptr[i + 1]; ++c) {
+                const int lt = pl->leaf_slot[pl->child_list[c]];
+                const int nop = pl->leaf_nop[lt];
+                double* ut = pl->panel.p + pl->leaf_poff[lt] + (size_t)nop * nop;
+                segs.push_back(GemmSeg{ut, ut, nop, nop, nop});
+            }
+        }
+        pl->parentSegs.upload(segs);
+        for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx) {
+            GemmProb g{};
+            g.C = lv.F.p + sidx * (size_t)lv.nf * lv.nf; g.ldc = lv.nf; g.M = lv.nf; g.N = lv.nf; g.lower = 1;
+            g.segs = pl->parentSegs.p + where[sidx].first; g.nseg = where[sidx].second; g.diag_one = lv.cw;
+            if (g.nseg == 0) { g.nseg = 0; g.K = 0; g.A = g.B = pl->W.p; }
+            ps[sidx] = g;
+        }
+        pl->gParentSyrk.upload(ps);
+        pl->parent_syrk = true;
+    }
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
@@ -587,22 +617,23 @@ static inline unsigned gemm_grid_x(long M, long N) {
 }
 
 template <int EPI>
-static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN) {
+static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true) {
     if (!nprob || maxM <= 0 || maxN <= 0) return;
-    const unsigned gx = gemm_grid_x(maxM, maxN);
+    const bool lds = pl->gemm_lds && allow_lds;
+    const unsigned gx = lds ? (unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)) : gemm_grid_x(maxM, maxN);
+    const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
     for (size_t off = 0; off < nprob; off += 65535) {
         const unsigned gy = (unsigned)std::min<size_t>(65535, nprob - off);
         dim3 grid(gx, gy);
-        const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
-        if (pl->d == 1) {
-            if (mode == 0) hipLaunchKernelGGL((k_gemm_nt<EPI, 1, 0>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
-            else if (mode == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 1, (EPI == EPI_COV ? 1 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
-            else hipLaunchKernelGGL((k_gemm_nt<EPI, 1, (EPI == EPI_COV ? 2 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp)
+        if (lds) {
+            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); }
+            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); }
         } else {
-            if (mode == 0) hipLaunchKernelGGL((k_gemm_nt<EPI, 2, 0>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
-            else if (mode == 1) hipLaunchKernelGGL((k_gemm_nt<EPI, 2, (EPI == EPI_COV ? 1 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
-            else hipLaunchKernelGGL((k_gemm_nt<EPI, 2, (EPI == EPI_COV ? 2 : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp);
+            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 1); else MRA_GEMM_LAUNCH(k_gemm_nt, 1, 2); }
+            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 1); else MRA_GEMM_LAUNCH(k_gemm_nt, 2, 2); }
         }
+#undef MRA_GEMM_LAUNCH
     }
 }
 
@@ -743,7 +774,7 @@ static void run_front_level(mra_plan* pl, int m) {
     const size_t nn = lv.nodes.size();
     if (!nn) return;
     { KTimer kt(pl, KF_FRONT_CHOL, lv.fl_fchol); launch_panel(pl, lv.gFrontChol.p, nn); }
-    { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na); }
+    { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na, false); }
 }
 
 static void run_assemble_level(mra_plan* pl, int m, bool with_identity) {
@@ -770,6 +801,11 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
     for (int m = m_from; m >= 0; --m) {
         const bool is_red = (m == pl->reduce_level);
         if (!(resume && m == m_from)) {
+            if (pl->direct_parent && m == pl->NL - 1) {
+                const LevelData& lvp = pl->lev[m];
+                KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk);
+                launch_gemm<EPI_SET>(pl, pl->gParentSyrk.p, lvp.nodes.size(), lvp.nf, lvp.nf, false);
+            } else
             run_assemble_level(pl, m, !is_red);
             if (is_red) {
                 // the reduce level's fronts are summed over ranks WITHOUT their identity blocks; the
@@ -934,7 +970,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
             const int ntl = pl->leaf_max_nop / 16;
             if (ntl <= 12) {
-                launch_panel(pl, pl->gLeafCholC.p, nl);
+                hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
                 if (fused) launch_trsm2(pl, pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p, nl, ntl, mt, mt);
                 else launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
@@ -942,7 +978,8 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
             }
         }
-        { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na); }
+        pl->direct_parent = fused && pl->parent_syrk && pl->reduce_level != pl->NL - 1;
+        if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false); }
         if (pred) {
             if (!fused || pl->leaf_max_nop / 16 > 12) {
                 KTimer kt(pl, KF_MISC, 0);
@@ -1162,6 +1199,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (!pl) return MRA_ERR_INVALID;
     if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
     if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
+    if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }
 
