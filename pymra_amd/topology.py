@@ -163,7 +163,12 @@ def _splits_small(coords: np.ndarray, rows: np.ndarray, knots: np.ndarray, newca
     return out
 
 
-def _grow(coords, rows, cand, levels_left, level, ident, r, J, flat: list) -> _TNode:
+def _grow(coords, rows, is_cand, levels_left, level, ident, r, J, flat: list) -> _TNode:
+    """One node of the replay.  ``is_cand`` is a global boolean array over caller rows: True while a
+    row has not been used as a knot by this node's ancestors (the reference's ``notKnots``,
+    MRANode.py:53, 83); a node's candidates are ``rows[is_cand[rows]]`` (ascending, like the
+    reference's)."""
+    cand = rows[is_cand[rows]]
     leaf = (levels_left == 0)
     n_c = len(cand)
     splitting = (not leaf) and n_c > max(r, J)
@@ -172,7 +177,8 @@ def _grow(coords, rows, cand, levels_left, level, ident, r, J, flat: list) -> _T
             knots = _knots_1d(coords, rows, cand, r)
         elif n_c > 1e2:
             # MRANode.py:191-193: consumes the *global* NumPy RNG, in DFS pre-order
-            pick = np.random.choice(np.arange(n_c), size=r, replace=False)
+            # (an int population draws the same permutation as the reference's np.arange(n_c))
+            pick = np.random.choice(n_c, size=r, replace=False)
             knots = np.sort(cand[pick])
         else:
             knots = _knots_kmeans(coords, rows, cand, r)
@@ -182,18 +188,17 @@ def _grow(coords, rows, cand, levels_left, level, ident, r, J, flat: list) -> _T
     node = _TNode(ident, level, rows, knots, leaf)
     flat.append(node)
     if splitting:
-        newcand = np.setdiff1d(cand, knots, assume_unique=True)
-        Jeff = min(J, len(newcand))
+        is_cand[knots] = False            # stays False for the whole subtree (and nobody else owns these rows)
         if len(rows) > 1e2:
             parts = _splits_geometric(coords, rows)
         else:
+            newcand = rows[is_cand[rows]]
+            Jeff = min(J, len(newcand))
             parts = _splits_small(coords, rows, knots, newcand, Jeff)
-        is_new = np.zeros(0, dtype=bool)
         for j, loc_idx in enumerate(parts):
             ch_rows = rows[loc_idx]
-            ch_cand = np.intersect1d(ch_rows, newcand, assume_unique=True)
             node.child_local.append(np.asarray(loc_idx, dtype=np.int64))
-            node.children.append(_grow(coords, ch_rows, ch_cand, levels_left - 1, level + 1,
+            node.children.append(_grow(coords, ch_rows, is_cand, levels_left - 1, level + 1,
                                        ident + str(j + 1), r, J, flat))
     return node
 
@@ -259,7 +264,9 @@ def build_topology(locs: np.ndarray, r: int, M: int, J: int) -> Topology:
     N, d = coords.shape
     flat: List[_TNode] = []
     all_rows = np.arange(N, dtype=np.int64)
-    root = _grow(coords, all_rows, all_rows, M, 0, "r", r, J, flat)
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    root = _grow(coords, all_rows, np.ones(N, dtype=bool), M, 0, "r", r, J, flat)
 
     # ---- leaf-ordered padded row layout --------------------------------------------------
     perm_chunks: List[np.ndarray] = []

@@ -199,3 +199,22 @@ def test_device_kernels_match_numpy_to_ulps(hip):
         big = want > 1e-13
         assert np.max(np.abs(got[big] - want[big]) / want[big]) < 2e-14, kind
         assert np.all(np.abs(got[~big] - want[~big]) <= 1e-11 * want[~big] + 1e-300)
+
+
+def test_rccl_allreduce_path_single_rank(hip):
+    """The on-device exchange (ncclAllReduce on the plan's stream, librccl loaded with dlopen) with a
+    communicator of size 1: must reproduce the plain run bit for bit in lik and to rounding elsewhere."""
+    from pymra_amd.sharding import sharded_run
+    cs = K.load_case("g64m")
+    pl, lik, mean, var = run_hip(hip, cs)
+    pl.close()
+    p = hip.HipPlan(cs["topo"], 0)
+    p.set_locs(cs["locs"]); p.set_obs(cs["y_obs"], cs["c"]["R"])
+    p.set_kernel(cs["spec"].kind, cs["spec"].l, cs["spec"].sig, cs["spec"].scale)
+    p.comm_init(hip.comm_unique_id(), 1, 0)
+    sharded_run(p, 0, None, True, True)                    # reduce level 0: the root front goes through RCCL
+    d, u = p.likelihood()
+    m2, v2 = p.predict()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
+    assert np.max(np.abs(m2 - mean)) < 1e-12 and np.max(np.abs(v2 - var)) < 1e-13
+    p.close()
