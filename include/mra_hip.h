@@ -91,7 +91,10 @@ int mra_plan_set_locs(mra_plan *plan, const double *locs_perm);
 int mra_plan_set_obs(mra_plan *plan, const double *y_perm, double R);
 
 /* Replaces: the `cov` callable when it is one of pyMRA's stationary kernels
- * (pyMRA/MRATools.py:256-301).  params = {l, sig, scale}; value = scale * k(D; l, sig). */
+ * (pyMRA/MRATools.py:256-301).  params = {l, sig, scale[, circular]}; value = scale * k(D; l, sig);
+ * circular != 0 (1-D only): D = min(|a-b|, 1-|a-b|), the torus branch of dist() (MRATools.py:232-239).
+ * kind == MRA_KERNEL_HOST (params ignored, call after mra_plan_set_obs): covariance values come from
+ * mra_plan_set_cov_block. */
 int mra_plan_set_kernel(mra_plan *plan, int kind, const double *params, int n_params);
 
 /* Diagnostics: out[i] = scale * k_kind(D[i]; l, sig) evaluated by the device code that the inference

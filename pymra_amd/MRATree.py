@@ -15,7 +15,8 @@ the library or without a GPU the constructor raises.
 ``cov`` plug-in: the user's two-argument callable is probed once with symbolic location handles.
 If it is built from this package's kernels (``mt.ExpCovFun``, ``mt.Matern32`` ... possibly times a
 scalar) the probe yields a ``KernelSpec`` and the kernel is evaluated on the GPU.  Other callables
-and dense matrices need the host-evaluated block path (``MRA_KERNEL_HOST``).
+and dense ``np.matrix``/``ndarray`` covariances are evaluated block by block on the host and uploaded
+(``MRA_KERNEL_HOST``, ``HipPlan.upload_host_cov``); everything else still runs on the GPU.
 
 ``critDepth`` is accepted for signature compatibility.  The reference's parallel mode forks one
 process per subtree at that depth (MRANode.py:90-104); the forked children inherit the same RNG
@@ -85,22 +86,23 @@ class MRATree(object):
         self.obs_inds = np.where(np.logical_not(np.isnan(obs_arr)))[0]
 
         spec = probe_cov(cov, self.d)
-        if spec is None:
-            raise NotImplementedError(
-                "cov must be built from pymra_amd.MRATools kernels (ExpCovFun, Matern32, Matern52, "
-                "GaussianCovFun, Iden; optionally times a scalar) so that it can be evaluated on the GPU; "
-                "opaque callables / dense matrices need the MRA_KERNEL_HOST block path, which this build "
-                "does not wire yet")
-        if spec.circular:
-            raise NotImplementedError("circular distances are not implemented on the device path")
-        self.kernel = spec
+        if spec is not None and spec.circular and self.d != 1:
+            raise ValueError("circular distances are defined for 1-D locations only")
+        if spec is None and not callable(cov) and not isinstance(cov, np.ndarray):
+            raise TypeError("cov must be a callable cov(locs1, locs2) or a dense N x N matrix")
+        self.kernel = spec          # None: opaque callable / dense matrix -> values come from the host
 
         logger.debug('r: %d, \tJ: %d,\tM: %d' % (self.r, self.J, self.M))
         self.topology = build_topology(np.asarray(locs, dtype=np.float64), r, self.M, self.J)
         self.plan = HipPlan(self.topology, device=device)
         self.plan.set_locs(locs)
         self.plan.set_obs(obs_arr, R)
-        self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+        if spec is not None:
+            self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale, spec.circular)
+        else:
+            # cov-callable plug-in for anything the device cannot evaluate itself (pyMRA/MRANode.py:73-80,
+            # 381-384): the host evaluates the raw covariance blocks, the GPU does everything else
+            self.plan.upload_host_cov(cov, locs, obs_arr)
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()
         if want_predict:
@@ -126,7 +128,7 @@ class MRATree(object):
         if spec is None:
             raise NotImplementedError("cov must be a device kernel")
         self.kernel = spec
-        self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+        self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale, spec.circular)
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()
         mean, var = self.plan.predict() if want_predict else (None, None)

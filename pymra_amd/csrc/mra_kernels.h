@@ -59,6 +59,7 @@ struct KernelParams {
     //   mode 0: t = c * D / l   (ExpCovFun: c=1,a1=a2=0; Matern32: c=sqrt3,a1=1; Matern52: c=sqrt5,a1=1,a2=1/3)
     //   mode 1: t = D^2 / (2 l^2)   (GaussianCovFun)          mode 2: [D == 0]   (Iden)
     int mode;
+    int circular;           // 1-D only: D = min(|a-b|, 1-|a-b|)  (torus of length 1, pyMRA/MRATools.py:232-239)
     double c_inv_l, inv_2l2, a1, a2, amp;
 };
 #define MRA_FAR_AWAY 1.0e150   /* coordinate of a phantom knot: every kernel gives exactly 0 there */
@@ -118,8 +119,12 @@ __device__ __forceinline__ double cov_of_dist(const KernelParams& kp, double D) 
 }
 
 template <int DIM>
-__device__ __forceinline__ double pair_dist2(const double* __restrict__ xa, const double* __restrict__ xb) {
-    if (DIM == 1) { const double dx = xa[0] - xb[0]; return dx * dx; }
+__device__ __forceinline__ double pair_dist2(const double* __restrict__ xa, const double* __restrict__ xb, int circular = 0) {
+    if (DIM == 1) {
+        double dx = fabs(xa[0] - xb[0]);
+        if (circular) dx = fmin(dx, fabs(1.0 - dx));
+        return dx * dx;
+    }
     const double dx = xa[0] - xb[0], dy = xa[1] - xb[1];
     return dx * dx + dy * dy;
 }
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
             else if (EPI == EPI_COV) {
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb, kp.circular)) - acc[s];
                 v = (bcol < 0) ? 0.0 : cv;
                 if (pb.rowmap) {
                     const int op = pb.rowmap[row];
@@ -228,6 +233,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
                 }
             } else {
                 v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+                if (pb.rowmap) {
+                    const int op = pb.rowmap[row];
+                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                }
             }
             *cp = v;
         }
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
             else if (EPI == EPI_COV) {
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb)) - acc[s];
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb, kp.circular)) - acc[s];
                 v = (bcol < 0) ? 0.0 : cv;
                 if (pb.rowmap) {
                     const int op = pb.rowmap[row];
@@ -333,6 +342,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
                 }
             } else {
                 v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+                if (pb.rowmap) {
+                    const int op = pb.rowmap[row];
+                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                }
             }
             *cp = v;
         }
@@ -823,7 +836,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
 #pragma unroll
                         for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM)) - acc[j];
+                        for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular)) - acc[j];
                     }
                     d4 upd = zero;
 #pragma unroll
@@ -1065,7 +1078,7 @@ __global__ void k_knot_kinv(const double* __restrict__ kx, const int* __restrict
         const double* wb = Wk + (node * cw + b) * K;
         double s = 0.0;
         for (int k = 0; k < K; ++k) s += wa[k] * wb[k];
-        v = (kp.mode == 0 ? cov_of_dist2<0>(kp, pair_dist2<DIM>(xa, xb)) : (kp.mode == 1 ? cov_of_dist2<1>(kp, pair_dist2<DIM>(xa, xb)) : cov_of_dist2<2>(kp, pair_dist2<DIM>(xa, xb)))) - s;
+        v = (kp.mode == 0 ? cov_of_dist2<0>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) : (kp.mode == 1 ? cov_of_dist2<1>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) : cov_of_dist2<2>(kp, pair_dist2<DIM>(xa, xb, kp.circular)))) - s;
     }
     Lp[(node * cw + a) * cw + b] = v;
 }

@@ -99,6 +99,7 @@ struct LevelData {
     long max_rows = 0;               // largest row range among the nodes
     DevVec<double> Lp, invP, F, invF;
     DevVec<GemmProb> gResid, gSchur, gUpdate;
+    std::vector<GemmProb> hResid;
     DevVec<KinvProb> gKinv;
     DevVec<PanelProb> gPriorChol, gFrontChol;
     DevVec<TrsmNode> gTrsmPrior, gTrsmPost;
@@ -148,6 +149,8 @@ struct mra_plan {
     DevVec<double*> leaf_ut;
     DevVec<LeafProb> gLeaf;
     DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
+    std::vector<GemmProb> hLeafResid;
+    std::vector<int> leaf_nobs_host;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
     DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
@@ -364,6 +367,7 @@ static void build_static(mra_plan* pl) {
             }
             as[s] = a;
         }
+        lv.hResid = resid;
         lv.gResid.upload(resid); lv.gSchur.upload(schur); lv.gUpdate.upload(upd); lv.gKinv.upload(kinv);
         lv.gPriorChol.upload(pch); lv.gFrontChol.upload(fch); lv.gTrsmPrior.upload(tpr); lv.gTrsmPost.upload(tpo);
         lv.gAsm.upload(as);
@@ -582,6 +586,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->gParentSyrk.upload(ps);
         pl->parent_syrk = true;
     }
+    pl->hLeafResid = gr; pl->leaf_nobs_host = nobs;
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
@@ -1119,11 +1124,43 @@ int mra_plan_set_obs(mra_plan* pl, const double* y, double R) {
 int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
     if (!pl) return MRA_ERR_INVALID;
     try {
-        if (kind == MRA_KERNEL_HOST)
-            throw MraError(MRA_ERR_STATE, "host-evaluated covariance blocks are not wired in this build");
+        if (kind == MRA_KERNEL_HOST) {
+            if (!pl->have_obs) throw MraError(MRA_ERR_STATE, "MRA_KERNEL_HOST needs mra_plan_set_obs first (leaf blocks are per observed row)");
+            HIP_TRY(hipSetDevice(pl->device));
+            // one padded block per node: non-leaf N_j x cw, leaf N_j x nop; leaves also C(x,x) per row
+            pl->cov_off.assign(pl->n_nodes + 1, 0);
+            for (int i = 0; i < pl->n_nodes; ++i) {
+                const long nr = pl->row1[i] - pl->row0[i];
+                const long ld = pl->leaf[i] ? pl->leaf_nop[pl->leaf_slot[i]] : pl->cw[pl->node_level[i]];
+                pl->cov_off[i + 1] = pl->cov_off[i] + nr * ld;
+            }
+            pl->covsrc.alloc(std::max<long>(pl->cov_off.back(), 1));
+            pl->covdiag.alloc(pl->P);
+            HIP_TRY(hipMemset(pl->covsrc.p, 0, pl->covsrc.n * sizeof(double)));
+            HIP_TRY(hipMemset(pl->covdiag.p, 0, pl->covdiag.n * sizeof(double)));
+            for (int m = 0; m < pl->n_levels; ++m) {
+                LevelData& lv = pl->lev[m];
+                for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
+                    lv.hResid[sl].Csrc = pl->covsrc.p + pl->cov_off[lv.nodes[sl]];
+                    lv.hResid[sl].ldcs = lv.cw;
+                }
+                if (!lv.nodes.empty()) lv.gResid.upload(lv.hResid);
+            }
+            for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+                pl->hLeafResid[t].Csrc = pl->covsrc.p + pl->cov_off[pl->leaf_nodes[t]];
+                pl->hLeafResid[t].ldcs = pl->leaf_nop[t];
+            }
+            if (!pl->leaf_nodes.empty()) pl->gLeafResid.upload(pl->hLeafResid);
+            pl->kp = KernelParams{};
+            pl->host_cov = true;
+            pl->have_kernel = true;
+            return MRA_OK;
+        }
         if (kind < 0 || kind > MRA_KERNEL_IDEN || !params || n < 3) throw MraError(MRA_ERR_INVALID, "unknown kernel kind or too few parameters (need l, sig, scale)");
         if (!(params[0] > 0.0)) throw MraError(MRA_ERR_INVALID, "length scale must be positive");
         pl->kp.kind = kind; pl->kp.d = pl->d; pl->kp.l = params[0]; pl->kp.sig = params[1]; pl->kp.scale = params[2];
+        pl->kp.circular = (n >= 4 && params[3] != 0.0) ? 1 : 0;
+        if (pl->kp.circular && pl->d != 1) throw MraError(MRA_ERR_INVALID, "circular distances are defined for 1-D locations only");
         derive_kernel_params(pl->kp);
         pl->host_cov = false;
         pl->have_kernel = true;
@@ -1132,9 +1169,31 @@ int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
 }
 
 int mra_plan_set_cov_block(mra_plan* pl, int32_t node, const double* C, int64_t n_rows, int64_t n_cols, const double* diag) {
-    (void)node; (void)C; (void)n_rows; (void)n_cols; (void)diag;
-    if (!pl) return MRA_ERR_INVALID;
-    return fail(pl, MraError(MRA_ERR_STATE, "host-evaluated covariance blocks are not wired in this build"));
+    if (!pl || !C) return MRA_ERR_INVALID;
+    try {
+        if (!pl->host_cov) throw MraError(MRA_ERR_STATE, "select MRA_KERNEL_HOST with mra_plan_set_kernel first");
+        if (node < 0 || node >= pl->n_nodes) throw MraError(MRA_ERR_INVALID, "node out of range");
+        HIP_TRY(hipSetDevice(pl->device));
+        const long nr = pl->row1[node] - pl->row0[node];
+        long ld, want_cols;
+        if (pl->leaf[node]) {
+            const int t = pl->leaf_slot[node];
+            ld = pl->leaf_nop[t]; want_cols = pl->leaf_nobs_host[t];
+            if (!diag) throw MraError(MRA_ERR_INVALID, "leaf blocks need diag (C(x,x) per row)");
+        } else {
+            ld = pl->cw[pl->node_level[node]]; want_cols = pl->knot_ptr[node + 1] - pl->knot_ptr[node];
+        }
+        if (n_rows != nr || n_cols != want_cols) {
+            char b[200];
+            snprintf(b, sizeof b, "block of node %d must be %ld x %ld (got %ld x %ld)", node, nr, want_cols, (long)n_rows, (long)n_cols);
+            throw MraError(MRA_ERR_INVALID, b);
+        }
+        if (n_cols > 0)
+            HIP_TRY(hipMemcpy2D(pl->covsrc.p + pl->cov_off[node], ld * sizeof(double), C, n_cols * sizeof(double),
+                                n_cols * sizeof(double), nr, hipMemcpyHostToDevice));
+        if (diag) HIP_TRY(hipMemcpy(pl->covdiag.p + pl->row0[node], diag, nr * sizeof(double), hipMemcpyHostToDevice));
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
 }
 
 int mra_run(mra_plan* pl, uint32_t flags) {
@@ -1228,6 +1287,7 @@ int mra_eval_kernel(int kind, const double* params, int n_params, const double* 
     if (!params || n_params < 3 || !D || !out || n <= 0 || kind < 0 || kind > MRA_KERNEL_IDEN) return MRA_ERR_INVALID;
     KernelParams kp{};
     kp.kind = kind; kp.d = 1; kp.l = params[0]; kp.sig = params[1]; kp.scale = params[2];
+    kp.circular = (n_params >= 4 && params[3] != 0.0) ? 1 : 0;
     derive_kernel_params(kp);
     double *dD = nullptr, *dO = nullptr;
     if (hipMalloc((void**)&dD, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&dO, n * sizeof(double)) != hipSuccess) {

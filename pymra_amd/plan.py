@@ -163,9 +163,55 @@ class HipPlan:
         yp = np.ascontiguousarray(yp)
         self._check(self.lib.mra_plan_set_obs(self._h, _ptr(yp), float(R)))
 
-    def set_kernel(self, kind, l, sig=1.0, scale=1.0):
-        par = np.array([l, sig, scale], dtype=np.float64)
-        self._check(self.lib.mra_plan_set_kernel(self._h, int(kind), _ptr(par), 3))
+    def set_kernel(self, kind, l, sig=1.0, scale=1.0, circular=False):
+        par = np.array([l, sig, scale, 1.0 if circular else 0.0], dtype=np.float64)
+        self._check(self.lib.mra_plan_set_kernel(self._h, int(kind), _ptr(par), 4))
+
+    def set_kernel_host(self):
+        """Covariance values will be supplied block by block (``set_cov_block``); call after ``set_obs``."""
+        self._check(self.lib.mra_plan_set_kernel(self._h, MRA_KERNEL_HOST, None, 0))
+
+    def set_cov_block(self, node, C, diag=None):
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        d = None if diag is None else np.ascontiguousarray(diag, dtype=np.float64)
+        self._check(self.lib.mra_plan_set_cov_block(self._h, int(node), _ptr(C), C.shape[0], C.shape[1],
+                                                    None if d is None else _ptr(d)))
+
+    def upload_host_cov(self, cov, locs, obs):
+        """Evaluate an opaque ``cov`` (callable on location arrays, or a dense N x N matrix) block by block
+        on the host - C(S_j, Q_j) for non-leaf nodes (pyMRA/MRANode.py:384), C(S_j, O_j) and C(x,x) for
+        leaves - and hand the blocks to the library."""
+        t = self.topo
+        X = np.asarray(locs, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1)
+        y = np.asarray(obs, dtype=np.float64).reshape(-1)
+        dense = None if callable(cov) else np.asarray(cov, dtype=np.float64)
+        if dense is not None and dense.shape != (t.N, t.N):
+            raise ValueError("a dense cov must be N x N")
+
+        def block(ra, rb):
+            if dense is not None:
+                return dense[np.ix_(ra, rb)]
+            return np.asarray(cov(X[ra], X[rb]), dtype=np.float64)
+
+        self.set_kernel_host()
+        for i in range(t.n_nodes):
+            rows = np.arange(t.node_row0[i], t.node_row1[i])
+            ra = t.src[rows]
+            if t.node_leaf[i]:
+                real = t.perm[rows] >= 0
+                obs_rows = rows[real & np.isfinite(np.where(real, y[ra], np.nan))]
+                rb = t.src[obs_rows]
+                C = block(ra, rb) if len(rb) else np.zeros((len(ra), 0))
+                if dense is not None:
+                    dg = np.diag(dense)[ra]
+                else:
+                    dg = np.diag(block(ra, ra))
+                self.set_cov_block(i, C, dg)
+            else:
+                kq = t.knot_rows[t.knot_ptr[i]:t.knot_ptr[i + 1]]
+                self.set_cov_block(i, block(ra, t.src[kq]))
 
     def set_option(self, option, value):
         self._check(self.lib.mra_plan_set_option(self._h, int(option), int(value)))

@@ -175,8 +175,8 @@ def test_api_errors(hip):
         pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1, M=3, J=3)               # int R (MRANode.py:85-88)
     with pytest.raises(AttributeError):
         pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1e-2, M=3)                 # 1-D needs J (MRATree.py:31-33)
-    with pytest.raises(NotImplementedError):
-        pymra_amd.MRATree(cs["locs"], 2, lambda a, b: np.exp(-np.abs(a - b.T)), cs["y_obs"], 1e-2, M=3, J=3)
+    with pytest.raises(TypeError):
+        pymra_amd.MRATree(cs["locs"], 2, "not a covariance", cs["y_obs"], 1e-2, M=3, J=3)
     tree = pymra_amd.MRATree(cs["locs"], 2, cov, cs["y_obs"], 1e-2, M=9, J=3)         # M clipped to 3
     assert tree.M == 3 and tree.J == 3 and tree.d == 1 and tree.r == 2
     assert abs(tree.getLikelihood()[0, 0] - float(cs["g"]["lik"])) < 1e-9
@@ -218,3 +218,63 @@ def test_rccl_allreduce_path_single_rank(hip):
     assert abs(d + u - lik) <= 1e-13 * abs(lik)
     assert np.max(np.abs(m2 - mean)) < 1e-12 and np.max(np.abs(v2 - var)) < 1e-13
     p.close()
+
+
+def test_opaque_callable_and_dense_matrix_cov(hip):
+    """cov plug-in surface (pyMRA/MRANode.py:73-80, 381-384): an arbitrary callable, and a dense N x N
+    matrix, go through the host-evaluated block path and agree with the device-kernel path."""
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    for name in ("g32", "c1", "u3"):
+        cs = K.load_case(name)
+        c = cs["c"]
+        np.random.seed(123)
+        dev = pymra_amd.MRATree(cs["locs"], c["r"], lambda a, b: cs["spec"].evaluate(a, b) if False else
+                                (mt.ExpCovFun(a, b, l=c["l"]) if c["kern"] == "exp" else mt.Matern32(a, b, l=c["l"], sig=c["sig"])),
+                                cs["y_obs"], c["R"], M=c["M"], J=c["J"])
+        assert dev.kernel is not None
+        opaque = lambda a, b: np.asarray(cs["spec"].evaluate(a, b)) + 0.0          # not recognisable by the probe
+        np.random.seed(123)
+        t1 = pymra_amd.MRATree(cs["locs"], c["r"], opaque, cs["y_obs"], c["R"], M=c["M"], J=c["J"])
+        assert t1.kernel is None
+        dense = np.asarray(cs["spec"].evaluate(cs["locs"], cs["locs"]))
+        np.random.seed(123)
+        t2 = pymra_amd.MRATree(cs["locs"], c["r"], np.matrix(dense), cs["y_obs"], c["R"], M=c["M"], J=c["J"])
+        tol = 1e-7 if name == "u3" else 1e-10
+        for t in (t1, t2):
+            assert abs(t.getLikelihood()[0, 0] - dev.getLikelihood()[0, 0]) <= tol * abs(dev.getLikelihood()[0, 0])
+            assert np.max(np.abs(np.asarray(t.predict()[0]) - np.asarray(dev.predict()[0]))) < max(tol, 1e-9)
+            assert K.rel(t.predict()[1], dev.predict()[1]) < (1e-5 if name == "u3" else 1e-8)
+
+
+def test_circular_distance_kernel(hip):
+    """1-D torus distances (pyMRA/MRATools.py:232-239) on the device vs the NumPy formula and vs the oracle."""
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    from oracle.mra_levelwise import run_levelwise
+    cs = K.load_case("c1")
+    c = cs["c"]
+    spec = mt.KernelSpec(mt.KIND_EXP, 0.2, 1.0, 1.0, circular=True)
+    tree = pymra_amd.MRATree(cs["locs"], c["r"], lambda a, b: mt.ExpCovFun(a, b, l=0.2, circular=True), cs["y_obs"], c["R"],
+                             M=c["M"], J=c["J"])
+    assert tree.kernel.circular
+    ref = run_levelwise(tree.topology, cs["locs"], spec, cs["y_obs"], c["R"])
+    assert abs(tree.getLikelihood()[0, 0] - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+    assert np.max(np.abs(np.asarray(tree.predict()[0]).ravel() - ref["mean"])) < 1e-10
+    assert K.rel(tree.predict()[1], ref["sd"]) < 1e-9
+
+
+def test_level_by_level_kernels_equal_fused_kernels(hip):
+    """Regular trees run the fused cascade kernels; the general level-by-level kernels (used for
+    irregular trees and host-evaluated covariances) must give the same numbers."""
+    for name in ("c1", "g64m", "c2"):
+        cs = K.load_case(name)
+        pl, lik, mean, var = run_hip(hip, cs)
+        pl.set_option(2, 0)                       # MRA_OPT_FUSED off
+        pl.set_option(3, 0)                       # MRA_OPT_GEMM_LDS off: direct-load GEMM
+        pl.run(True, True)
+        d, u = pl.likelihood()
+        m2, v2 = pl.predict()
+        assert abs(d + u - lik) <= 1e-12 * abs(lik)
+        assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10
+        pl.close()
