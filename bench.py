@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--likelihood-only", action="store_true")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
+                    help="transport of the one front all-reduce for --gpus > 1: RCCL on the device (default) or "
+                         "host export/import + torch.distributed gloo (rehearsal on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
     c = CONFIGS[args.config]
 
@@ -110,6 +113,8 @@ def main():
 
     if P.device_count() < 1:
         raise SystemExit("bench.py needs an AMD GPU (libmra_hip has no CPU fallback)")
+    if os.environ.get("MRA_BENCH_SINGLE_DEVICE") == "1":      # rehearsal: every rank on GPU 0 (only with --exchange gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     # ---- set-up (untimed): inputs, tree, plan, upload ----------------------------------------------
@@ -124,15 +129,42 @@ def main():
     pl.set_obs(y_obs, c["R"])
     kind = mt.KIND_MATERN32 if c["kern"] == "m32" else mt.KIND_EXP
     pl.set_kernel(kind, c["l"], c["sig"], 1.0)
-    if world > 1:
-        uid = [P.comm_unique_id() if rank == 0 else None]
+    host_allreduce = None
+    exchange = args.exchange
+    if world > 1 and exchange == "rccl":
+        ok = 1
+        try:
+            uid = [P.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                                # pragma: no cover - depends on the box
+            uid, ok = [None], 0
+            print("rank %d: RCCL unique id failed: %s" % (rank, e), file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
-        pl.comm_init(uid[0], world, rank)
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                pl.comm_init(uid[0], world, rank)
+            except Exception as e:                            # pragma: no cover
+                ok = 0
+                print("rank %d: RCCL init failed: %s" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            # every rank falls back together: host export/import + gloo all-reduce of the same buffer
+            exchange = "gloo (RCCL unavailable)"
+            pl.close()
+            pl = P.HipPlan(local, local_rank)
+            pl.set_locs(locs); pl.set_obs(y_obs, c["R"]); pl.set_kernel(kind, c["l"], c["sig"], 1.0)
+    if world > 1 and exchange != "rccl":
+        def host_allreduce(buf):
+            t = torch.from_numpy(np.ascontiguousarray(buf))
+            dist.all_reduce(t)
+            return t.numpy()
     t3 = time.perf_counter()
     predict = not args.likelihood_only
 
     def step():
-        sharded_run(pl, red, None, True, predict)
+        sharded_run(pl, red, host_allreduce, True, predict)
 
     def barrier():
         if dist is not None:
@@ -207,7 +239,7 @@ def main():
                        "r0": c["r"], "kernel": "Matern32" if c["kern"] == "m32" else "ExpCovFun", "l": c["l"],
                        "frac_obs": c["frac"], "R": c["R"], "nodes": n_nodes,
                        "mode": "likelihood" if args.likelihood_only else "likelihood+predict",
-                       "parallelism": "subtree-shard x%d, 1 all-reduce" % world if world > 1 else "single GPU"},
+                       "parallelism": ("subtree-shard x%d, 1 all-reduce (%s)" % (world, exchange)) if world > 1 else "single GPU"},
             "likelihood": d + u,
             "ms_per_step_with_kernel_events": 1e3 * elapsed / args.steps,
             "device_phase_ms": timers,

@@ -1,0 +1,37 @@
+"""Timing-only emulation of one rank of an N-way sharded run on a single GPU: rank 0's local tree is
+run with the split entry points, re-importing its own front buffer (numbers are NOT the full
+likelihood - only the time per step and the per-kernel breakdown are meaningful)."""
+import os, sys, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from pymra_amd import plan as P
+from pymra_amd.sharding import shard_topology
+from pymra_amd.topology import build_topology
+import pymra_amd.MRATools as mt
+
+c = bench.CONFIGS["c3"]
+locs, y_obs = bench.make_inputs(c)
+topo = build_topology(locs, c["r"], c["M"], c["J"])
+for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    local, red = shard_topology(topo, world, 0)
+    pl = P.HipPlan(local, 0); pl.set_locs(locs); pl.set_obs(y_obs, c["R"]); pl.set_kernel(mt.KIND_MATERN32, c["l"], c["sig"], 1.0)
+    if red >= 0: pl.set_reduce_level(red)
+    def step():
+        if red < 0: pl.run(True, True); return
+        pl.run(True, True, split=True); buf = pl.reduce_export(); pl.reduce_import(buf); pl.resume()
+    for _ in range(3): step()
+    pl.set_option(1, 1)
+    t0 = time.perf_counter(); n = 10
+    acc = None
+    for _ in range(n):
+        step(); ks = pl.kernel_stats()
+        if acc is None: acc = ks
+        else:
+            for a, b in zip(acc, ks): a["ms"] += b["ms"]; a["launches"] += b["launches"]
+    dt = (time.perf_counter() - t0) / n * 1e3
+    print("world %d: rank-0 local P=%d nodes=%d  %.3f ms/step (incl. host export/import)  reduce buf %.1f KB" % (world, local.P, local.n_nodes, dt, (len(pl.reduce_export()) * 8 / 1024) if False else 0))
+    for k in acc:
+        if k["launches"]: print("      %-58s %5.1f launches %7.3f ms" % (k["name"], k["launches"] / n, k["ms"] / n))
+    pl.close()
