@@ -755,110 +755,97 @@ struct CascadeArgs {
     int ut_yrow;              // Ut row of y
 };
 
-template <int CWT, int NLMAX, int DIM, int MODE>
-__global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelParams kp) {
-    // One workgroup = up to 8 row tiles that share the same node on every level (same leaf / same
-    // knot set), one tile per wave.  Per level the node's operands (Wk, strictly-lower tiles of L,
-    // inverted diagonal blocks) are staged in LDS once and read by all waves.
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+// tiles staged for level m: Wk [jb][k*CWT+kt] (CWT*m*CWT), strictly-lower L (NTRI), inverted diagonals (CWT)
+template <int CWT>
+__device__ __forceinline__ constexpr int cascade_level_tiles(int m) { return CWT * m * CWT + CWT * (CWT - 1) / 2 + CWT; }
+template <int CWT>
+__device__ __forceinline__ constexpr int cascade_level_off(int m) {      // tiles of all levels < m
+    return CWT * CWT * (m * (m - 1) / 2) + m * (CWT * (CWT - 1) / 2 + CWT);
+}
+
+template <int CWT>
+__device__ __forceinline__ void cascade_stage_level(const CascadeArgs& ar, int m, int slot, double* __restrict__ ldsb) {
     constexpr int CW = CWT * 16;
     constexpr int NTRI = CWT * (CWT - 1) / 2;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const long t0 = ar.wg_tile0[blockIdx.x];
-    const int nt_wg = ar.wg_ntiles[blockIdx.x];
-    const bool active = wave < nt_wg;
-    const long t = t0 + (active ? wave : 0);
-    const int prow = pi16(r);
-    const d4 zero = {0, 0, 0, 0};
-    long myrow;
-    bool phantom_row = false;
-    if (ar.knot_mode) {
-        const int rr = ar.tile_rows[t * 16 + r];
-        phantom_row = rr < 0;
-        myrow = phantom_row ? 0 : rr;
-    } else {
-        myrow = ar.tile_row0[t] + r;
+    const CascadeLevel lv = ar.lev[m];
+    const double* Wk = lv.Wk + (long)slot * CW * (m * CW);
+    const double* Lm = lv.L + (long)slot * CW * CW;
+    const double* inv = lv.invd + (long)slot * CWT * 256;
+    const int nwk = CWT * m * CWT;
+    for (int e = threadIdx.x; e < (nwk + NTRI + CWT) * 128; e += blockDim.x) {
+        const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
+        const double* src;
+        if (tile < nwk) {
+            const int jb = tile / (m * CWT), kk = tile % (m * CWT);
+            src = Wk + (long)(jb * 16 + row) * (m * CW) + kk * 16 + c2;
+        } else if (tile < nwk + NTRI) {
+            const int tt = tile - nwk;
+            int jb = 1;
+            while ((jb + 1) * jb / 2 <= tt) ++jb;
+            const int kb = tt - jb * (jb - 1) / 2;
+            src = Lm + (long)(jb * 16 + row) * CW + kb * 16 + c2;
+        } else {
+            src = inv + (long)(tile - nwk - NTRI) * 256 + row * 16 + c2;
+        }
+        *(double2*)(ldsb + tile * 256 + row * 16 + c2) = *(const double2*)src;
     }
-    double xr[DIM];
+}
+
+template <int CWT, int NLMAX, int DIM, int MODE>
+__device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, const KernelParams& kp, int m, int slot,
+                                                      const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
+                                                      const double* xr, int prow, int q) {
+    constexpr int CW = CWT * 16;
+    constexpr int NTRI = CWT * (CWT - 1) / 2;
+    const d4 zero = {0, 0, 0, 0};
+    const double* kx = ar.lev[m].kx + (long)slot * CW * DIM;
+    const int nwk = CWT * m * CWT;
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
-    const int* chain = ar.tile_chain + t0 * 8;          // identical for every tile of the workgroup
-    d4 w[NLMAX][CWT];
+    for (int jb = 0; jb < CWT; ++jb) {
+        d4 acc = zero;
 #pragma unroll
-    for (int m = 0; m < NLMAX; ++m) {
-        if (m <= ar.mlast) {
-            const int slot = chain[m];
-            const CascadeLevel lv = ar.lev[m];
-            const double* Wk = lv.Wk + (long)slot * CW * (m * CW);
-            const double* kx = lv.kx + (long)slot * CW * DIM;
-            const double* Lm = lv.L + (long)slot * CW * CW;
-            const double* inv = lv.invd + (long)slot * CWT * 256;
-            // ---- stage this level's operands: tiles [jb][k*CWT+kt] of Wk, then L (jb>kb), then invd
-            const int nwk = CWT * m * CWT;
-            __syncthreads();
-            for (int e = threadIdx.x; e < (nwk + NTRI + CWT) * 128; e += blockDim.x) {
-                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
-                const double* src;
-                if (tile < nwk) {
-                    const int jb = tile / (m * CWT), kk = tile % (m * CWT);
-                    src = Wk + (long)(jb * 16 + row) * (m * CW) + kk * 16 + c2;
-                } else if (tile < nwk + NTRI) {
-                    const int tt = tile - nwk;
-                    int jb = 1;
-                    while ((jb + 1) * jb / 2 <= tt) ++jb;
-                    const int kb = tt - jb * (jb - 1) / 2;
-                    src = Lm + (long)(jb * 16 + row) * CW + kb * 16 + c2;
-                } else {
-                    src = inv + (long)(tile - nwk - NTRI) * 256 + row * 16 + c2;
-                }
-                *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
-            }
-            __syncthreads();
-            if (active) {
+        for (int k = 0; k < NLMAX; ++k) {
+            if (k < m) {
 #pragma unroll
-                for (int jb = 0; jb < CWT; ++jb) {
-                    d4 acc = zero;
+                for (int kt = 0; kt < CWT; ++kt) {
+                    const d4 a = *(const d4*)(ldsb + (jb * (m * CWT) + k * CWT + kt) * 256 + prow * 16 + 4 * q);
 #pragma unroll
-                    for (int k = 0; k < NLMAX; ++k) {
-                        if (k < m) {
-#pragma unroll
-                            for (int kt = 0; kt < CWT; ++kt) {
-                                const d4 a = *(const d4*)(lds + (jb * (m * CWT) + k * CWT + kt) * 256 + prow * 16 + 4 * q);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) acc = mfma16(a[j], w[k][kt][j], acc);
-                            }
-                        }
-                    }
-                    d4 res;
-                    {
-                        double kc[4 * DIM];                     // coordinates of this lane's 4 knots (phantoms: far away)
-                        const double* kp4 = kx + (long)(jb * 16 + 4 * q) * DIM;
-#pragma unroll
-                        for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular)) - acc[j];
-                    }
-                    d4 upd = zero;
-#pragma unroll
-                    for (int kb = 0; kb < CWT; ++kb) {
-                        if (kb < jb) {
-                            const d4 a = *(const d4*)(lds + (nwk + jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) upd = mfma16(a[j], w[m][kb][j], upd);
-                        }
-                    }
-                    res -= upd;
-                    const d4 ia = *(const d4*)(lds + (nwk + NTRI + jb) * 256 + prow * 16 + 4 * q);
-                    d4 xx = zero;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], res[j], xx);
-                    w[m][jb] = xx;
+                    for (int j = 0; j < 4; ++j) acc = mfma16(a[j], w[k][kt][j], acc);
                 }
             }
         }
+        d4 res;
+        {
+            double kc[4 * DIM];                     // coordinates of this lane's 4 knots (phantoms: far away)
+            const double* kp4 = kx + (long)(jb * 16 + 4 * q) * DIM;
+#pragma unroll
+            for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular)) - acc[j];
+        }
+        d4 upd = zero;
+#pragma unroll
+        for (int kb = 0; kb < CWT; ++kb) {
+            if (kb < jb) {
+                const d4 a = *(const d4*)(ldsb + (nwk + jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], w[m][kb][j], upd);
+            }
+        }
+        res -= upd;
+        const d4 ia = *(const d4*)(ldsb + (nwk + NTRI + jb) * 256 + prow * 16 + 4 * q);
+        d4 xx = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], res[j], xx);
+        w[m][jb] = xx;
     }
-    if (!active) return;
-    // ---- outputs
+}
+
+template <int CWT, int NLMAX>
+__device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int* chain, long t, long myrow, bool phantom_row,
+                                                d4 (&w)[NLMAX][CWT], int r, int q) {
+    constexpr int CW = CWT * 16;
+    const d4 zero = {0, 0, 0, 0};
     if (ar.knot_mode) {
         const int mo = ar.mlast + 1;
         const int slotk = chain[mo];
@@ -874,45 +861,114 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
                 }
             }
         }
+        return;
+    }
+    double* o = ar.W + myrow * ar.ldw;
+    double ssq = 0.0;
+#pragma unroll
+    for (int m = 0; m < NLMAX; ++m) {
+        if (m <= ar.mlast) {
+#pragma unroll
+            for (int jb = 0; jb < CWT; ++jb) {
+                const d4 v = w[m][jb];
+                *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+                ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            }
+        }
+    }
+    if (ar.var_out) {
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
+    }
+    if (ar.obs_pos) {
+        const int op = ar.obs_pos[myrow];
+        if (op >= 0) {
+            const int lf = ar.tile_leaf[t];
+            double* ut = ar.leaf_ut[lf];
+            const long nop = ar.leaf_nop[lf];
+#pragma unroll
+            for (int m = 0; m < NLMAX; ++m) {
+                if (m <= ar.mlast) {
+#pragma unroll
+                    for (int jb = 0; jb < CWT; ++jb) {
+                        const d4 v = w[m][jb];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
+                    }
+                }
+            }
+            if (q == 0) ut[(long)ar.ut_yrow * nop + op] = ar.y[myrow];
+        }
+    }
+}
+
+// One workgroup = the row tiles of one leaf (FULL) or the knot tiles of one node (KNOT): they share
+// the same node on every level.  STAGE_ALL: the operands of ALL levels (Wk, strictly-lower tiles of L,
+// inverted diagonal blocks) are staged in LDS once, then every wave walks its tiles down the levels
+// with no further barrier.  Otherwise (operands do not fit in 160 KB) they are staged level by level
+// and each wave owns exactly one tile.
+template <int CWT, int NLMAX, int DIM, int MODE, bool STAGE_ALL>
+__global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int nwave = blockDim.x >> 6;
+    const long t0 = ar.wg_tile0[blockIdx.x];
+    const int nt_wg = ar.wg_ntiles[blockIdx.x];
+    const int prow = pi16(r);
+    const int* chain = ar.tile_chain + t0 * 8;          // identical for every tile of the workgroup
+    if (STAGE_ALL) {
+#pragma unroll
+        for (int m = 0; m < NLMAX; ++m)
+            if (m <= ar.mlast) cascade_stage_level<CWT>(ar, m, chain[m], lds + cascade_level_off<CWT>(m) * 256);
+        __syncthreads();
+        for (int tw = wave; tw < nt_wg; tw += nwave) {
+            const long t = t0 + tw;
+            long myrow;
+            bool phantom_row = false;
+            if (ar.knot_mode) {
+                const int rr = ar.tile_rows[t * 16 + r];
+                phantom_row = rr < 0;
+                myrow = phantom_row ? 0 : rr;
+            } else {
+                myrow = ar.tile_row0[t] + r;
+            }
+            double xr[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
+            d4 w[NLMAX][CWT];
+#pragma unroll
+            for (int m = 0; m < NLMAX; ++m)
+                if (m <= ar.mlast)
+                    cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds + cascade_level_off<CWT>(m) * 256, w, xr, prow, q);
+            cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q);
+        }
     } else {
-        double* o = ar.W + myrow * ar.ldw;
-        double ssq = 0.0;
+        const bool active = wave < nt_wg;
+        const long t = t0 + (active ? wave : 0);
+        long myrow;
+        bool phantom_row = false;
+        if (ar.knot_mode) {
+            const int rr = ar.tile_rows[t * 16 + r];
+            phantom_row = rr < 0;
+            myrow = phantom_row ? 0 : rr;
+        } else {
+            myrow = ar.tile_row0[t] + r;
+        }
+        double xr[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
+        d4 w[NLMAX][CWT];
 #pragma unroll
         for (int m = 0; m < NLMAX; ++m) {
             if (m <= ar.mlast) {
-#pragma unroll
-                for (int jb = 0; jb < CWT; ++jb) {
-                    const d4 v = w[m][jb];
-                    *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
-                    ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-                }
+                __syncthreads();
+                cascade_stage_level<CWT>(ar, m, chain[m], lds);
+                __syncthreads();
+                if (active) cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds, w, xr, prow, q);
             }
         }
-        if (ar.var_out) {
-            ssq += __shfl_xor(ssq, 16, 64);
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
-        }
-        if (ar.obs_pos) {
-            const int op = ar.obs_pos[myrow];
-            if (op >= 0) {
-                const int lf = ar.tile_leaf[t];
-                double* ut = ar.leaf_ut[lf];
-                const long nop = ar.leaf_nop[lf];
-#pragma unroll
-                for (int m = 0; m < NLMAX; ++m) {
-                    if (m <= ar.mlast) {
-#pragma unroll
-                        for (int jb = 0; jb < CWT; ++jb) {
-                            const d4 v = w[m][jb];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
-                        }
-                    }
-                }
-                if (q == 0) ut[(long)ar.ut_yrow * nop + op] = ar.y[myrow];
-            }
-        }
+        if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q);
     }
 }
 

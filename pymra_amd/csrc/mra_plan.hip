@@ -175,8 +175,12 @@ struct mra_plan {
     DevVec<long> ft_row0, ft_wg0;
     DevVec<int> ft_chain, ft_wgn;
     long n_ftiles = 0, n_fwg = 0;
-    size_t cascade_lds = 0;
-    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the cascade kernels
+    size_t cascade_lds = 0, cascade_lds_all = 0;
+    bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
+    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels
+    DevVec<long> ft_wg0_leaf;
+    DevVec<int> ft_wgn_leaf;
+    long n_fwg_leaf = 0;
     // host cov staging (MRA_KERNEL_HOST)
     std::vector<long> cov_off;           // per node offset into covsrc
     std::vector<double> cov_host, covdiag_host;
@@ -445,12 +449,13 @@ static void build_static(mra_plan* pl) {
                 f.gKinv.upload(gk);
             }
         }
-        std::vector<long> r0s, fwg0;
-        std::vector<int> chains, fwgn, tleaf;
+        std::vector<long> r0s, fwg0, lwg0;
+        std::vector<int> chains, fwgn, tleaf, lwgn;
         for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
             const int i = pl->leaf_nodes[t];
             int ch[8];
             chain_of(i, ch);
+            lwg0.push_back((long)r0s.size()); lwgn.push_back((int)((pl->row1[i] - pl->row0[i]) / 16));
             for (long p = pl->row0[i]; p < pl->row1[i]; p += 16) {
                 if (((p - pl->row0[i]) / 16) % pl->cascade_wpw == 0) {
                     fwg0.push_back((long)r0s.size());
@@ -467,6 +472,10 @@ static void build_static(mra_plan* pl) {
         {
             const int cwt = pl->CWT, mmax = pl->NL - 1;
             pl->cascade_lds = (size_t)(cwt * mmax * cwt + cwt * (cwt - 1) / 2 + cwt) * 2048;
+            const int nl = pl->NL;
+            pl->cascade_lds_all = (size_t)(cwt * cwt * (nl * (nl - 1) / 2) + nl * (cwt * (cwt - 1) / 2 + cwt)) * 2048;
+            pl->cascade_stage_all = pl->cascade_lds_all <= 160 * 1024;
+            pl->ft_wg0_leaf.upload(lwg0); pl->ft_wgn_leaf.upload(lwgn); pl->n_fwg_leaf = (long)lwg0.size();
         }
     }
 }
@@ -674,8 +683,17 @@ static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int
 template <int CWT, int NLMAX, int DIM, int MODE>
 static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw), pl->cascade_lds, pl->stream, ar, pl->kp);
+    if (!attr) {
+        hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (pl->cascade_stage_all)
+        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 512),
+                           pl->cascade_lds_all, pl->stream, ar, pl->kp);
+    else
+        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw),
+                           pl->cascade_lds, pl->stream, ar, pl->kp);
 }
 template <int CWT, int NLMAX>
 static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
@@ -730,7 +748,7 @@ static void run_prior_fused(mra_plan* pl) {
         for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_resid + pl->lev[m].fl_trsm;
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
-        ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.n_wg = pl->n_fwg;
+        ar.knot_mode = 0; ar.mlast = pl->NL - 1;
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
         if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
             ar.obs_pos = pl->obs_pos.p; ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p;
@@ -739,7 +757,8 @@ static void run_prior_fused(mra_plan* pl) {
             for (int m = 0; m < pl->NL; ++m) ar.ut_off[m] = pl->coff[m] - pl->asuf[pl->NL];
             ar.ut_yrow = pl->Ka - pl->asuf[pl->NL];
         }
-        ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
+        if (pl->cascade_stage_all) { ar.n_wg = pl->n_fwg_leaf; ar.wg_tile0 = pl->ft_wg0_leaf.p; ar.wg_ntiles = pl->ft_wgn_leaf.p; }
+        else { ar.n_wg = pl->n_fwg; ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p; }
         ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p;
         launch_cascade_any(pl, ar);
     }

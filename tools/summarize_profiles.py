@@ -1,0 +1,76 @@
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh into the small files kept under profiles/."""
+import collections, csv, glob, json, os, shutil, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "gpurun_out", "profiles_" + tag)
+os.makedirs(dst, exist_ok=True)
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+ks = one("kt/*/*_kernel_stats.csv")
+if ks:
+    shutil.copy(ks, os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
+
+def family(name, grid, maxgrid):
+    """rocprof kernel name (+ grid) -> bench.py kernel family name"""
+    if name.startswith("void k_prior_cascade"):
+        return "k_trsm_rows prior / fused prior cascade" if grid == maxgrid.get("cascade") else "k_gemm_nt<COV> prior resid"
+    if name.startswith("void k_predict_cascade"): return "k_gemm_nt<SUB> predict update / fused predict cascade"
+    if name.startswith("void k_gemm_nt_lds<2"): return "k_gemm_nt<COV> leaf resid" if grid == maxgrid.get("cov") else "small kernels"
+    if name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt<SUB> leaf update"
+    if name.startswith("void k_gemm_nt<0"): return "k_gemm_nt<SET> leaf syrk"
+    if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front schur"
+    if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_panel_chol leaf"
+    if name.startswith("k_panel_chol"): return "k_panel_chol prior+front"
+    return "small kernels"
+
+summary = {}
+for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    f = one(sub + "/*/*_counter_collection.csv")
+    if not f:
+        continue
+    rows = list(csv.DictReader(open(f)))
+    mg = {}
+    for r in rows:
+        n, g = r["Kernel_Name"], int(r["Grid_Size"])
+        if n.startswith("void k_prior_cascade"): mg["cascade"] = max(mg.get("cascade", 0), g)
+        if n.startswith("void k_gemm_nt_lds<2"): mg["cov"] = max(mg.get("cov", 0), g)
+    acc = collections.defaultdict(list)
+    disp = collections.defaultdict(set)
+    for r in rows:
+        fam = family(r["Kernel_Name"], int(r["Grid_Size"]), mg)
+        acc[fam].append(float(r["Counter_Value"]))
+        disp[fam].add(r["Dispatch_Id"])
+    for fam, v in acc.items():
+        summary.setdefault(fam, {})[ctr + "_KB_per_launch_mean"] = sum(v) / len(v)
+        summary[fam]["launches_seen_" + ctr] = len(v)
+for fam, d in summary.items():
+    if "FETCH_SIZE_KB_per_launch_mean" in d and "WRITE_SIZE_KB_per_launch_mean" in d:
+        # gfx950: FETCH_SIZE reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section)
+        d["hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE_KB_per_launch_mean"] + d["WRITE_SIZE_KB_per_launch_mean"]) * 1024.0
+json.dump(summary, open(os.path.join(dst, tag + "_pmc_traffic_by_kernel_family.json"), "w"), indent=1)
+
+f = one("sq/*/*_counter_collection.csv")
+if f:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60] + " | grid " + r["Grid_Size"]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, c in acc.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        if m.get("dur_us", 0) < 50:
+            continue
+        cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        m["mfma_pipe_busy_frac"] = (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0) / cyc if cyc else None
+        m["clock_GHz"] = cyc / (m["dur_us"] * 1e3) if m.get("dur_us") else None
+        out[k] = m
+    json.dump(out, open(os.path.join(dst, tag + "_pmc_sq_summary.json"), "w"), indent=1)
+b = os.path.join(src, "bench.json")
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
+print("summaries in", dst, sorted(os.listdir(dst)))
