@@ -159,6 +159,11 @@ struct GemmProb {
     const struct GemmSeg* segs;
     int nseg;
     int diag_one;           // SET: add 1 on the diagonal for row == col < diag_one (front identity block)
+    // k_gemm_nt_lds only: rows of A gathered through idxA (-1: phantom).  With sym_diag (COV) the result is
+    // the square block kernel(x_a, x_b) - A B^T + diag_add * I over the SAME index list on both sides,
+    // identity on phantoms: the leaves' C = v_m(o,o) + R I in likelihood-only runs
+    const int* idxA;
+    int sym_diag;
 };
 struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; };
 
@@ -270,8 +275,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
     const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves
     // ---- staging role: thread -> (row, 32-byte chunk) of A and of B
     const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
-    const bool a_ok = (M0 + srow) < pb.M;
-    const double* ap = pb.A + (long)(M0 + (a_ok ? srow : 0)) * pb.lda + sch;
+    bool a_ok = (M0 + srow) < pb.M;
+    long arow = M0 + srow;
+    if (a_ok && pb.idxA) { const int ia = pb.idxA[arow]; a_ok = ia >= 0; arow = a_ok ? ia : 0; }
+    const double* ap = pb.A + (a_ok ? arow : 0) * pb.lda + sch;
     long brow = N0 + srow;
     bool b_ok = brow < pb.N;
     if (b_ok && pb.idxB) { const int ib = pb.idxB[brow]; b_ok = ib >= 0; brow = b_ok ? ib : 0; }
@@ -334,8 +341,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
             else if (EPI == EPI_COV) {
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb, kp.circular)) - acc[s];
-                v = (bcol < 0) ? 0.0 : cv;
+                long xrow = row;
+                if (pb.idxA) { const int ia = pb.idxA[row]; xrow = ia; }
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (xrow < 0 ? 0 : xrow) * DIM, xb, kp.circular)) - acc[s];
+                v = (bcol < 0 || xrow < 0) ? 0.0 : cv;
+                if (pb.sym_diag && row == col) v = (bcol < 0) ? 1.0 : v + pb.diag_add;
                 if (pb.rowmap) {
                     const int op = pb.rowmap[row];
                     if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);

@@ -148,7 +148,7 @@ struct mra_plan {
     DevVec<int> obs_idx, obs_pos, leaf_nobs, leaf_nop_dev, ft_leaf;
     DevVec<double*> leaf_ut;
     DevVec<LeafProb> gLeaf;
-    DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate;
+    DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate, gLeafResidLik;
     std::vector<GemmProb> hLeafResid;
     std::vector<int> leaf_nobs_host;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
@@ -513,7 +513,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
     std::vector<LeafProb> lp(nl);
-    std::vector<GemmProb> gr(nl), gs(nl), gu(nl);
+    std::vector<GemmProb> gr(nl), gs(nl), gu(nl), grl(nl);
     std::vector<PanelProb> pf(nl), pk(nl), pc(nl);
     std::vector<Trsm2Prob> tf(nl), tk(nl);
     pl->leaf_max_tiles_full = pl->leaf_max_tiles_lik = 0;
@@ -537,6 +537,14 @@ static void build_leaf(mra_plan* pl, const double* y) {
         g.M = (int)nr; g.N = nop; g.K = Kanc; g.lower = 0;
         g.rowmap = pl->obs_pos.p + r0; g.C2 = Pn; g.diag_add = pl->R;
         gr[t] = g;
+        {
+            // likelihood-only runs need just C = v_m(o,o) + R I: both sides gathered through the observation list
+            GemmProb c{};
+            c.A = pl->W.p + a0; c.lda = pl->ldw; c.idxA = q.obs; c.B = c.A; c.ldb = pl->ldw; c.idxB = q.obs;
+            c.C = Pn; c.ldc = nop; c.XA = pl->X.p; c.XB = pl->X.p;
+            c.M = nop; c.N = nop; c.K = Kanc; c.lower = 1; c.sym_diag = 1; c.diag_add = pl->R;
+            grl[t] = c;
+        }
         pl->fl_leaf_resid += 2.0 * nr * nop * Kanc;
         double* inv = pl->leafInv.p + pl->leaf_ioff[t];
         pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
@@ -596,6 +604,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->parent_syrk = true;
     }
     pl->hLeafResid = gr; pl->leaf_nobs_host = nobs;
+    pl->gLeafResidLik.upload(grl);
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
@@ -974,14 +983,18 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     // ---- 2. leaves
     const size_t nl = pl->leaf_nodes.size();
     if (nl) {
+        const bool c_only = !pred && fused && pl->gemm_lds && pl->leaf_max_nop / 16 <= 12;
         {
-            KTimer kt(pl, KF_LEAF_RESID, pl->fl_leaf_resid);
+            KTimer kt(pl, KF_LEAF_RESID, c_only ? 0.0 : pl->fl_leaf_resid);
             if (pl->host_cov) launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
+            else if (c_only) launch_gemm<EPI_COV>(pl, pl->gLeafResidLik.p, nl, pl->leaf_max_nop, pl->leaf_max_nop);
             else launch_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
         }
         if (pl->leaf_max_nop > 0) {
             KTimer kt(pl, KF_MISC, 0);
-            if (pl->leaf_max_nop / 16 <= 12) {
+            if (c_only) {
+                // nothing to do: the gathered COV product wrote the whole C block including phantom identities
+            } else if (pl->leaf_max_nop / 16 <= 12) {
                 // C comes from the COV epilogue, Ut from the gather inside k_trsm_rows2: only the phantom rows remain
                 hipLaunchKernelGGL(k_leaf_cphantom, dim3((unsigned)nl), dim3(256), 0, pl->stream, pl->gLeaf.p, pl->leaf_nobs.p);
             } else {
