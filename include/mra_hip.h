@@ -38,6 +38,7 @@ extern "C" {
 #define MRA_KERNEL_MATERN52    2   /* Matern52                                          :281-285 */
 #define MRA_KERNEL_GAUSSIAN    3   /* GaussianCovFun sig exp(-D^2/(2 l^2))              :297-301 */
 #define MRA_KERNEL_IDEN        4   /* Iden           [D == 0]                           :256-262 */
+#define MRA_KERNEL_KANTER      5   /* KanterCovFun   compact taper, radius = l          :305-324 */
 #define MRA_KERNEL_HOST        100 /* values supplied block by block (any cov callable or a dense
                                       matrix, pyMRA/MRANode.py:73-80, 381-384)                   */
 

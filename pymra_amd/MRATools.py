@@ -30,16 +30,18 @@ KIND_MATERN32 = 1
 KIND_MATERN52 = 2
 KIND_GAUSSIAN = 3
 KIND_IDEN = 4
+KIND_KANTER = 5
 
 
 class SymbolicLocs:
     """Stand-in for a location array while ``MRATree`` probes the ``cov`` callable."""
-    __slots__ = ("tag", "ndim", "shape")
+    __slots__ = ("tag", "ndim", "shape", "data")
 
-    def __init__(self, tag, d):
+    def __init__(self, tag, d, data=None):
         self.tag = tag
         self.ndim = 2
         self.shape = (0, d)
+        self.data = data            # the caller's full location array (needed by KanterCovFun(radius=int))
 
     def __len__(self):
         return 1            # `if len(locs2)` in the reference's dist(): "second set given"
@@ -134,8 +136,59 @@ def _iden(l1, l2, l, sig, circular):
     return out
 
 
+def _kanter(l1, l2, l, sig, circular):
+    """Kanter's compactly supported taper with radius l (pyMRA/MRATools.py:318-323)."""
+    D = np.array(dist(l1, l2, circular)) / l
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p2 = 2 * np.pi * D
+        R = (1 - D) * np.sin(p2) / p2 + 1 / np.pi * (1 - np.cos(p2)) / p2
+    R[D > 1] = 0
+    R[D == 0] = 1
+    return R
+
+
 _HOST_KERNELS = {KIND_EXP: _exp, KIND_MATERN32: _m32, KIND_MATERN52: _m52, KIND_GAUSSIAN: _gauss,
-                 KIND_IDEN: _iden}
+                 KIND_IDEN: _iden, KIND_KANTER: _kanter}
+
+
+def determine_radius(k, h, ndim=2):
+    """Taper radius that leaves about k grid points inside the support (mesh width h); same rule as
+    pyMRA/MRATools.py:329-388: 1 grid row -> int(k/2) h; otherwise the ring of the square lattice whose
+    cumulative point count is nearest to k."""
+    if ndim == 1:
+        return int(k / 2) * h
+    if k == 0:
+        raise ValueError("Ensemble size must be stricly positive")
+    s = np.floor(np.sqrt(k))
+    sf = s - 1 if s % 2 == 0 else s
+    if k == sf ** 2:
+        return h * 1.01 * (sf - 1) / 2 * np.sqrt(2)
+    base = (sf - 1) / 2.0
+    counts = [sf ** 2]
+    while counts[-1] < (sf + 2) ** 2:
+        step = 4 if (len(counts) == 1 or (sf + 2) ** 2 - counts[-1] == 4) else 8
+        counts.append(counts[-1] + step)
+    counts = np.asarray(counts)
+    ind = counts.searchsorted(k)
+    pick = ind - 1 if k <= (counts[ind - 1] + counts[ind]) / 2.0 else ind
+    if pick == 0:
+        return h * base * np.sqrt(2) + h * 0.01
+    return h * np.sqrt((base + 1) ** 2 + (pick - 1) ** 2) + h * 0.01
+
+
+def KanterCovFun(locs, locs2=np.array([]), radius=1.0, circular=False):
+    """radius: float = taper radius; int = target number of points in the support (resolved from the grid
+    spacing of ``locs`` like the reference does; on the device path from the tree's full location set)."""
+    src = locs.data if isinstance(locs, SymbolicLocs) else locs
+    if isinstance(radius, int):
+        if src is None:
+            raise ValueError("KanterCovFun(radius=int) needs the locations to derive the mesh width")
+        xs = np.sort(np.unique(src[:, 0]))
+        ndim = len(np.unique(src[:, 1])) if src.shape[1] > 1 else 1
+        radius = determine_radius(radius, xs[1] - xs[0], ndim=ndim)
+    if _symbolic(locs, locs2):
+        return KernelSpec(KIND_KANTER, radius, 1.0, 1.0, circular)
+    return _kanter(locs, locs2, radius, 1.0, circular)
 
 
 def Iden(locs, locs2=np.array([]), l=1, circular=False):

@@ -54,14 +54,14 @@ class RootView:
         self.children = []
 
 
-def probe_cov(cov, d):
+def probe_cov(cov, d, locs=None):
     """Return a KernelSpec if ``cov`` is expressible as one of the device kernels, else None."""
     if isinstance(cov, mt.KernelSpec):
         return cov
     if not callable(cov):
         return None
     try:
-        out = cov(mt.SymbolicLocs("a", d), mt.SymbolicLocs("b", d))
+        out = cov(mt.SymbolicLocs("a", d, locs), mt.SymbolicLocs("b", d, locs))
     except Exception:
         return None
     return out if isinstance(out, mt.KernelSpec) else None
@@ -85,7 +85,7 @@ class MRATree(object):
         obs_arr = np.asarray(obs, dtype=np.float64)
         self.obs_inds = np.where(np.logical_not(np.isnan(obs_arr)))[0]
 
-        spec = probe_cov(cov, self.d)
+        spec = probe_cov(cov, self.d, np.asarray(locs, dtype=np.float64))
         if spec is not None and spec.circular and self.d != 1:
             raise ValueError("circular distances are defined for 1-D locations only")
         if spec is None and not callable(cov) and not isinstance(cov, np.ndarray):
@@ -124,7 +124,7 @@ class MRATree(object):
     # re-evaluate with other kernel parameters on the same tree (plan reuse for MLE loops,
     # README.md:96-104 builds a new MRATree per objective call)
     def reevaluate(self, cov, want_predict=False):
-        spec = probe_cov(cov, self.d)
+        spec = probe_cov(cov, self.d, np.asarray(self.locs, dtype=np.float64))
         if spec is None:
             raise NotImplementedError("cov must be a device kernel")
         self.kernel = spec

@@ -58,6 +58,7 @@ struct KernelParams {
     // derived on the host (derive_kernel_params): value = amp * (1 + a1 t + a2 t^2) * exp(-t)
     //   mode 0: t = c * D / l   (ExpCovFun: c=1,a1=a2=0; Matern32: c=sqrt3,a1=1; Matern52: c=sqrt5,a1=1,a2=1/3)
     //   mode 1: t = D^2 / (2 l^2)   (GaussianCovFun)          mode 2: [D == 0]   (Iden)
+    //   mode 3: Kanter taper of radius l (KanterCovFun, compact support), c_inv_l = 1/radius
     int mode;
     int circular;           // 1-D only: D = min(|a-b|, 1-|a-b|)  (torus of length 1, pyMRA/MRATools.py:232-239)
     double c_inv_l, inv_2l2, a1, a2, amp;
@@ -110,12 +111,18 @@ __device__ __forceinline__ double sqrt_pos(double x) {
 template <int MODE>
 __device__ __forceinline__ double cov_of_dist2(const KernelParams& kp, double D2) {
     if (MODE == 2) return (D2 == 0.0) ? kp.amp : 0.0;
+    if (MODE == 3) {                                 // pyMRA/MRATools.py:318-323
+        const double D = fmin(sqrt_pos(D2) * kp.c_inv_l, 2.0);
+        const double p2 = 6.283185307179586 * D;
+        const double v = (1.0 - D) * sin(p2) / p2 + 0.3183098861837907 * (1.0 - cos(p2)) / p2;
+        return kp.amp * ((D == 0.0) ? 1.0 : ((D > 1.0) ? 0.0 : v));
+    }
     const double t = (MODE == 1) ? D2 * kp.inv_2l2 : sqrt_pos(D2) * kp.c_inv_l;
     const double poly = __builtin_fma(__builtin_fma(kp.a2, t, kp.a1), t, 1.0);
     return kp.amp * (poly * exp_neg(t));
 }
 __device__ __forceinline__ double cov_of_dist(const KernelParams& kp, double D) {
-    return kp.mode == 0 ? cov_of_dist2<0>(kp, D * D) : (kp.mode == 1 ? cov_of_dist2<1>(kp, D * D) : cov_of_dist2<2>(kp, D * D));
+    return kp.mode == 0 ? cov_of_dist2<0>(kp, D * D) : (kp.mode == 1 ? cov_of_dist2<1>(kp, D * D) : (kp.mode == 2 ? cov_of_dist2<2>(kp, D * D) : cov_of_dist2<3>(kp, D * D)));
 }
 
 template <int DIM>
@@ -1144,7 +1151,7 @@ __global__ void k_knot_kinv(const double* __restrict__ kx, const int* __restrict
         const double* wb = Wk + (node * cw + b) * K;
         double s = 0.0;
         for (int k = 0; k < K; ++k) s += wa[k] * wb[k];
-        v = (kp.mode == 0 ? cov_of_dist2<0>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) : (kp.mode == 1 ? cov_of_dist2<1>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) : cov_of_dist2<2>(kp, pair_dist2<DIM>(xa, xb, kp.circular)))) - s;
+        v = cov_of_dist(kp, sqrt(pair_dist2<DIM>(xa, xb, kp.circular))) - s;
     }
     Lp[(node * cw + a) * cw + b] = v;
 }

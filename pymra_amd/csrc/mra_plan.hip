@@ -28,6 +28,7 @@ static void derive_kernel_params(KernelParams& kp) {
         case 1: c = 1.7320508075688772; kp.a1 = 1.0; break;
         case 2: c = 2.23606797749979; kp.a1 = 1.0; kp.a2 = 1.0 / 3.0; break;
         case 3: kp.mode = 1; break;
+        case 5: kp.mode = 3; kp.amp = kp.scale; break;                // KanterCovFun(radius = l)
         default: kp.mode = 2; kp.amp = kp.scale; break;
     }
     kp.c_inv_l = c / kp.l;
@@ -650,11 +651,11 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
         dim3 grid(gx, gy);
 #define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp)
         if (lds) {
-            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); }
-            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); }
+            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 3); }
+            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 3); }
         } else {
-            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 1); else MRA_GEMM_LAUNCH(k_gemm_nt, 1, 2); }
-            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 1); else MRA_GEMM_LAUNCH(k_gemm_nt, 2, 2); }
+            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt, 1, 3); }
+            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt, 2, 3); }
         }
 #undef MRA_GEMM_LAUNCH
     }
@@ -711,11 +712,13 @@ static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
     if (pl->d == 1) {
         if (mode == 0) launch_cascade_inst<CWT, NLMAX, 1, 0>(pl, ar);
         else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 1, 1>(pl, ar);
-        else launch_cascade_inst<CWT, NLMAX, 1, 2>(pl, ar);
+        else if (mode == 2) launch_cascade_inst<CWT, NLMAX, 1, 2>(pl, ar);
+        else launch_cascade_inst<CWT, NLMAX, 1, 3>(pl, ar);
     } else {
         if (mode == 0) launch_cascade_inst<CWT, NLMAX, 2, 0>(pl, ar);
         else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 2, 1>(pl, ar);
-        else launch_cascade_inst<CWT, NLMAX, 2, 2>(pl, ar);
+        else if (mode == 2) launch_cascade_inst<CWT, NLMAX, 2, 2>(pl, ar);
+        else launch_cascade_inst<CWT, NLMAX, 2, 3>(pl, ar);
     }
 }
 static void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) {
@@ -1188,7 +1191,7 @@ int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
             pl->have_kernel = true;
             return MRA_OK;
         }
-        if (kind < 0 || kind > MRA_KERNEL_IDEN || !params || n < 3) throw MraError(MRA_ERR_INVALID, "unknown kernel kind or too few parameters (need l, sig, scale)");
+        if (kind < 0 || kind > MRA_KERNEL_KANTER || !params || n < 3) throw MraError(MRA_ERR_INVALID, "unknown kernel kind or too few parameters (need l, sig, scale)");
         if (!(params[0] > 0.0)) throw MraError(MRA_ERR_INVALID, "length scale must be positive");
         pl->kp.kind = kind; pl->kp.d = pl->d; pl->kp.l = params[0]; pl->kp.sig = params[1]; pl->kp.scale = params[2];
         pl->kp.circular = (n >= 4 && params[3] != 0.0) ? 1 : 0;
@@ -1316,7 +1319,7 @@ int mra_plan_info(mra_plan* pl, int64_t* out, int cap) {
 
 // Diagnostics: evaluate a device kernel on n distances (pyMRA/MRATools.py:265-301 on D = dist(...)).
 int mra_eval_kernel(int kind, const double* params, int n_params, const double* D, int64_t n, double* out) {
-    if (!params || n_params < 3 || !D || !out || n <= 0 || kind < 0 || kind > MRA_KERNEL_IDEN) return MRA_ERR_INVALID;
+    if (!params || n_params < 3 || !D || !out || n <= 0 || kind < 0 || kind > MRA_KERNEL_KANTER) return MRA_ERR_INVALID;
     KernelParams kp{};
     kp.kind = kind; kp.d = 1; kp.l = params[0]; kp.sig = params[1]; kp.scale = params[2];
     kp.circular = (n_params >= 4 && params[3] != 0.0) ? 1 : 0;

@@ -156,7 +156,8 @@ def test_other_device_kernels_against_oracle(hip):
     from oracle.mra_levelwise import run_levelwise
     base = K.load_case("g32")
     for spec in (mt.KernelSpec(mt.KIND_MATERN52, 0.25, 1.3), mt.KernelSpec(mt.KIND_GAUSSIAN, 0.05, 0.8),
-                 mt.KernelSpec(mt.KIND_MATERN32, 0.3, 1.0, scale=2.5)):
+                 mt.KernelSpec(mt.KIND_MATERN32, 0.3, 1.0, scale=2.5), mt.KernelSpec(mt.KIND_KANTER, 0.35),
+                 mt.KernelSpec(mt.KIND_IDEN, 1.0, 1.0, scale=0.7)):
         cs = dict(base, spec=spec)
         pl, lik, mean, var = run_hip(hip, cs)
         ref = run_levelwise(cs["topo"], cs["locs"], spec, cs["y_obs"], cs["c"]["R"])
@@ -191,11 +192,14 @@ def test_device_kernels_match_numpy_to_ulps(hip):
     D = np.concatenate([[0.0], np.abs(rng.normal(size=20000)) * 0.7, 10.0 ** rng.uniform(-9, 2, size=20000)])
     x = np.zeros((1, 1))
     for kind, l, sig in ((mt.KIND_EXP, 0.3, 1.0), (mt.KIND_MATERN32, 0.3, 1.7), (mt.KIND_MATERN52, 2.0, 0.4),
-                         (mt.KIND_GAUSSIAN, 0.8, 1.2)):
+                         (mt.KIND_GAUSSIAN, 0.8, 1.2), (mt.KIND_KANTER, 0.9, 1.0)):
         spec = mt.KernelSpec(kind, l, sig, 1.5)
         want = np.asarray(spec.evaluate(x, D.reshape(-1, 1))).ravel()
         got = hip.eval_kernel(kind, l, sig, 1.5, D)
         # exp(-t) carries the rounding of its argument: relative error ~ t * 2^-53, so compare where t <~ 30
+        if kind == mt.KIND_KANTER:      # the taper's two terms cancel near D = 1: compare on the kernel's own scale
+            assert np.max(np.abs(got - want)) < 1e-14 * 1.5
+            continue
         big = want > 1e-13
         assert np.max(np.abs(got[big] - want[big]) / want[big]) < 2e-14, kind
         assert np.all(np.abs(got[~big] - want[~big]) <= 1e-11 * want[~big] + 1e-300)
