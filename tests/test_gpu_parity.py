@@ -282,3 +282,51 @@ def test_level_by_level_kernels_equal_fused_kernels(hip):
         assert abs(d + u - lik) <= 1e-12 * abs(lik)
         assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10
         pl.close()
+
+
+@pytest.mark.parametrize("n,r,M,fused", [(128, 64, 3, True), (128, 64, 5, False), (96, 48, 2, True), (64, 16, 3, True)])
+def test_wide_blocks_and_deep_trees(hip, n, r, M, fused):
+    """r0 = 64 (4 column tiles per level: C5-like) on the fused path (CWT=4) and, when the cascades'
+    register budget is exceeded (4 tiles x 5 levels), on the general level-by-level path; r0 = 48 (3 tiles) is
+    not a fused block width and also takes the general path."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    np.random.seed(21)
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y = np.random.normal(size=(n * n, 1))
+    y_obs = np.where(np.random.uniform(size=(n * n, 1)) < 0.35, y, np.nan)
+    topo = build_topology(locs, r, M, 4)
+    spec = mt.KernelSpec(mt.KIND_MATERN32, 0.25, 1.2)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=2e-2))
+    pl, lik, mean, var = run_hip(hip, cs)
+    ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
+    assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-9
+    assert K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+    pl.close()
+
+
+def test_large_fully_observed_leaves(hip):
+    """Leaves with several hundred observations (more than the 192 that fit the LDS-resident solve): the
+    general panel Cholesky path."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    np.random.seed(4)
+    n = 48
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y_obs = np.random.normal(size=(n * n, 1))                     # everything observed
+    topo = build_topology(locs, 16, 1, 4)
+    assert topo.n_nodes == 5 and (topo.node_row1[1] - topo.node_row0[1]) >= 576
+    spec = mt.KernelSpec(mt.KIND_EXP, 0.3)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=5e-2))
+    pl, lik, mean, var = run_hip(hip, cs)
+    ref = run_levelwise(topo, locs, spec, y_obs, 5e-2)
+    assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-9
+    assert K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+    pl.run(True, False)
+    d, u = pl.likelihood()
+    assert abs(d + u - lik) <= 1e-12 * abs(lik)
+    pl.close()
