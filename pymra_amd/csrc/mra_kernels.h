@@ -504,31 +504,24 @@ __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict_
 //  idling three of four waves (k_panel_chol).  Left-looking over 16x16 tiles in vec layout; the
 //  matrix stays in global memory (L1/L2-hot, written and re-read by the same wave).
 // ------------------------------------------------------------------------------------------------
-template <int NTMAX>
-__global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
-                                                    double* __restrict__ dnode, int* __restrict__ err) {
-    __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16];
-    __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int ip = blockIdx.x * 4 + wave;
-    if (ip >= nprob) return;
-    const PanelProb pb = probs[ip];
-    const int nt = pb.ne;
+// One wave factorises an nt*16 square matrix in place (lower part), writes the inverted diagonal blocks
+// and returns sum(log diag L).  sd / si: 2 KB of LDS scratch each, private to the wave.
+__device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld, int nt, double* __restrict__ invd,
+                                                 double* sd, double* si, int lane, bool& bad) {
+    const int r = lane & 15, q = lane >> 4;
     const int prow = pi16(r);
     const d4 zero = {0, 0, 0, 0};
     double logacc = 0.0;
-    double* sd = sdiag[wave];
-    double* si = sinv[wave];
 #pragma unroll 1
     for (int jb = 0; jb < nt; ++jb) {
         // ---- diagonal tile: left-looking update, then factor + invert
         {
-            double* tp = pb.P + (long)(jb * 16 + r) * pb.ld + jb * 16 + 4 * q;
+            double* tp = P + (long)(jb * 16 + r) * ld + jb * 16 + 4 * q;
             d4 acc = *(const d4*)tp;
             d4 upd = zero;
             for (int kb = 0; kb < jb; ++kb) {
-                const d4 a = *(const d4*)(pb.P + (long)(jb * 16 + prow) * pb.ld + kb * 16 + 4 * q);
-                const d4 b = *(const d4*)(pb.P + (long)(jb * 16 + r) * pb.ld + kb * 16 + 4 * q);
+                const d4 a = *(const d4*)(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
+                const d4 b = *(const d4*)(P + (long)(jb * 16 + r) * ld + kb * 16 + 4 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
             }
@@ -540,28 +533,26 @@ __global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__
             double a[16], m[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? sd[r * 16 + k] : 0.0;
-            bool bad = false;
             logacc += chol16_inv(a, m, r, bad);
             if (lane < 16) {
-                double* dp = pb.P + (long)(jb * 16 + lane) * pb.ld + jb * 16;
-                double* ip2 = pb.invd + (long)jb * 256;
+                double* dp = P + (long)(jb * 16 + lane) * ld + jb * 16;
+                double* ip2 = invd + (long)jb * 256;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) dp[k] = a[k];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { si[i * 16 + lane] = m[i]; ip2[i * 16 + lane] = m[i]; }
-                if (bad && lane == 0) atomicMax(err, pb.node + 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
         const d4 ia = *(const d4*)(si + prow * 16 + 4 * q);
         // ---- rows below
         for (int ib = jb + 1; ib < nt; ++ib) {
-            double* tp = pb.P + (long)(ib * 16 + r) * pb.ld + jb * 16 + 4 * q;
+            double* tp = P + (long)(ib * 16 + r) * ld + jb * 16 + 4 * q;
             d4 acc = *(const d4*)tp;
             d4 upd = zero;
             for (int kb = 0; kb < jb; ++kb) {
-                const d4 a = *(const d4*)(pb.P + (long)(jb * 16 + prow) * pb.ld + kb * 16 + 4 * q);
-                const d4 b = *(const d4*)(pb.P + (long)(ib * 16 + r) * pb.ld + kb * 16 + 4 * q);
+                const d4 a = *(const d4*)(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
+                const d4 b = *(const d4*)(P + (long)(ib * 16 + r) * ld + kb * 16 + 4 * q);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
             }
@@ -573,7 +564,24 @@ __global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__
         }
         __threadfence_block();          // this wave's stores before its own later loads (other lanes)
     }
-    if (lane == 0) dnode[pb.node] = 2.0 * logacc;
+    return logacc;
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
+                                                    double* __restrict__ dnode, int* __restrict__ err) {
+    __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16];
+    __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ip = blockIdx.x * 4 + wave;
+    if (ip >= nprob) return;
+    const PanelProb pb = probs[ip];
+    bool bad = false;
+    const double logacc = chol_wave_body(pb.P, pb.ld, pb.ne, pb.invd, sdiag[wave], sinv[wave], lane, bad);
+    if (lane == 0) {
+        dnode[pb.node] = 2.0 * logacc;
+        if (bad) atomicMax(err, pb.node + 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -770,6 +778,11 @@ struct CascadeArgs {
     const double* y;          // [P]
     int ut_off[8];            // Ut row of level m's first column = ut_off[m]
     int ut_yrow;              // Ut row of y
+    // KNOT: finish the node in the same launch: kInv = kernel(knots,knots) - Wk Wk^T, its Cholesky factor
+    // and inverted diagonal blocks (nullptr: leave that to separate launches)
+    double* Lp_out;           // [node][cw][cw]
+    double* invd_out;         // [node][cwt][256]
+    int* err;
 };
 
 // tiles staged for level m: Wk [jb][k*CWT+kt] (CWT*m*CWT), strictly-lower L (NTRI), inverted diagonals (CWT)
@@ -986,6 +999,46 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             }
         }
         if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q);
+    }
+    if (ar.knot_mode && ar.Lp_out) {
+        // ---- the node's kInv, factor and inverted diagonal blocks, still in this launch
+        constexpr int CW = CWT * 16;
+        double* s_sd = lds;            // the staged operands are dead by now: reuse the dynamic LDS as scratch
+        double* s_si = lds + 256;
+        const int mo = ar.mlast + 1;
+        const int slotk = chain[mo];
+        const int Kw = mo * CW;
+        const double* Wk = ar.Wk_out + (long)slotk * CW * Kw;
+        const double* kx = ar.lev[mo].kx + (long)slotk * CW * DIM;
+        double* Lp = ar.Lp_out + (long)slotk * CW * CW;
+        const d4 zero = {0, 0, 0, 0};
+        __syncthreads();                                  // every wave's Wk rows are in global memory
+        for (int idx = wave; idx < CWT * (CWT + 1) / 2; idx += nwave) {
+            int ib = 0;
+            while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
+            const int jb = idx - ib * (ib + 1) / 2;
+            d4 acc = zero;
+            for (int kk = 0; kk < Kw; kk += 16) {
+                const d4 a = *(const d4*)(Wk + (long)(jb * 16 + prow) * Kw + kk + 4 * q);
+                const d4 b = *(const d4*)(Wk + (long)(ib * 16 + r) * Kw + kk + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
+            }
+            double xi[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xi[c] = kx[(long)(ib * 16 + r) * DIM + c];
+            d4 res;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xi, kx + (long)(jb * 16 + 4 * q + j) * DIM, kp.circular)) - acc[j];
+            *(d4*)(Lp + (long)(ib * 16 + r) * CW + jb * 16 + 4 * q) = res;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            bool bad = false;
+            chol_wave_body(Lp, CW, CWT, ar.invd_out + (long)slotk * CWT * 256, s_sd, s_si, lane, bad);
+            if (bad && lane == 0) atomicMax(ar.err, 1000000 + slotk);
+        }
     }
 }
 

@@ -60,7 +60,7 @@ enum KFam {
     KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
 };
 static const char* kfam_name[KF_COUNT] = {
-    "k_gemm_nt<COV> prior resid", "k_panel_chol prior", "k_trsm_rows prior / fused prior cascade", "k_gemm_nt<COV> leaf resid",
+    "k_gemm_nt<COV> prior resid", "k_panel_chol prior / fused knot pass", "k_trsm_rows prior / fused prior cascade", "k_gemm_nt<COV> leaf resid",
     "k_panel_chol leaf", "k_gemm_nt<SET> leaf syrk", "k_gemm_nt<SUB> leaf update", "k_panel_chol front",
     "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update / fused predict cascade", "small kernels"};
 
@@ -700,10 +700,10 @@ static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
     }
     if (pl->cascade_stage_all)
         hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 512),
-                           pl->cascade_lds_all, pl->stream, ar, pl->kp);
+                           std::max<size_t>(pl->cascade_lds_all, 4096), pl->stream, ar, pl->kp);
     else
         hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw),
-                           pl->cascade_lds, pl->stream, ar, pl->kp);
+                           std::max<size_t>(pl->cascade_lds, 4096), pl->stream, ar, pl->kp);
 }
 template <int CWT, int NLMAX>
 static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
@@ -741,19 +741,16 @@ static void run_prior_fused(mra_plan* pl) {
     }
     base.X = pl->X.p; base.W = pl->W.p; base.ldw = pl->ldw;
     for (int m = 0; m < pl->NL; ++m) {
+        // one launch per level: knot rows cascade -> Wk, kInv, Cholesky factor, inverted diagonal blocks
         LevelData& lv = pl->lev[m];
-        const size_t nn = lv.nodes.size();
-        if (m > 0) {
-            KTimer kt(pl, KF_PRIOR_RESID, 0);
-            CascadeArgs ar = base;
-            ar.knot_mode = 1; ar.mlast = m - 1; ar.n_wg = pl->fl[m].n_kwg;
-            ar.wg_tile0 = pl->fl[m].kt_wg0.p; ar.wg_ntiles = pl->fl[m].kt_wgn.p;
-            ar.tile_rows = pl->fl[m].kt_rows.p; ar.tile_chain = pl->fl[m].kt_chain.p; ar.tile_knot0 = pl->fl[m].kt_knot0.p;
-            ar.Wk_out = pl->fl[m].Wk.p;
-            launch_cascade_any(pl, ar);
-        }
-        { KTimer kt(pl, KF_MISC, 0); launch_gemm<EPI_COV>(pl, pl->fl[m].gKinv.p, nn, cw, cw); }
-        { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
+        KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol);
+        CascadeArgs ar = base;
+        ar.knot_mode = 1; ar.mlast = m - 1; ar.n_wg = pl->fl[m].n_kwg;
+        ar.wg_tile0 = pl->fl[m].kt_wg0.p; ar.wg_ntiles = pl->fl[m].kt_wgn.p;
+        ar.tile_rows = pl->fl[m].kt_rows.p; ar.tile_chain = pl->fl[m].kt_chain.p; ar.tile_knot0 = pl->fl[m].kt_knot0.p;
+        ar.Wk_out = pl->fl[m].Wk.p;
+        ar.Lp_out = lv.Lp.p; ar.invd_out = lv.invP.p; ar.err = pl->errflag.p;
+        launch_cascade_any(pl, ar);
     }
     {
         double fl = 0;
