@@ -154,6 +154,8 @@ struct mra_plan {
     std::vector<int> leaf_nobs_host;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
+    size_t n_trsm_small = 0;            // the *Plain arrays are ordered: leaves with nt <= 8 first
+    int trsm_small_nt = 0, trsm_small_tiles_full = 0, trsm_small_tiles_lik = 0;
     DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
     DevVec<GemmSeg> parentSegs;
     bool parent_syrk = false, direct_parent = false;
@@ -611,7 +613,26 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
     for (auto& e : tf) e.gtiles = 0;
     for (auto& e : tk) e.gtiles = 0;
-    pl->gLeafTrsmFullPlain.upload(tf); pl->gLeafTrsmLikPlain.upload(tk);
+    {
+        // most leaves need at most 8 column tiles: they get the 8-tile instance (fewer registers, two
+        // workgroups per CU), the few larger ones the 12-tile instance
+        std::vector<Trsm2Prob> tf2, tk2;
+        pl->trsm_small_nt = pl->trsm_small_tiles_full = pl->trsm_small_tiles_lik = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t t = 0; t < nl; ++t) {
+                const bool small = tf[t].nt <= 8;
+                if (small != (pass == 0)) continue;
+                tf2.push_back(tf[t]); tk2.push_back(tk[t]);
+                if (small) {
+                    pl->trsm_small_nt = std::max(pl->trsm_small_nt, tf[t].nt);
+                    pl->trsm_small_tiles_full = std::max(pl->trsm_small_tiles_full, tf[t].ntiles);
+                    pl->trsm_small_tiles_lik = std::max(pl->trsm_small_tiles_lik, tk[t].ntiles);
+                }
+            }
+        pl->n_trsm_small = 0;
+        for (size_t t = 0; t < nl; ++t) if (tf[t].nt <= 8) ++pl->n_trsm_small;
+        pl->gLeafTrsmFullPlain.upload(tf2); pl->gLeafTrsmLikPlain.upload(tk2);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1009,7 +1030,13 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             if (ntl <= 12) {
                 hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
-                if (fused) launch_trsm2(pl, pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p, nl, ntl, mt, mt);
+                if (fused) {
+                    const Trsm2Prob* base = pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p;
+                    const size_t ns = pl->n_trsm_small;
+                    const int mts = pred ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
+                    if (ns) launch_trsm2(pl, base, ns, pl->trsm_small_nt, mts, mts);
+                    if (nl > ns) launch_trsm2(pl, base + ns, nl - ns, ntl, mt, mt);
+                }
                 else launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
             } else {
                 launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
