@@ -38,9 +38,11 @@ logger = logging.getLogger("pyMRA.MRATree")
 
 
 class RootView:
-    """The attributes of the reference's root ``Node`` that callers read."""
+    """The attributes of the reference's root ``Node`` that callers read (pyMRA/MRANode.py:26-45, 378-391,
+    444-520).  ``d, u, mean, var`` come from the GPU pass; ``knots, B, kInv, k`` (the root's prior blocks,
+    cov(locs, knots) etc.) are evaluated lazily on the host from the kernel when somebody asks."""
 
-    def __init__(self, d, u, mean, var, N, topo):
+    def __init__(self, d, u, mean, var, N, topo, locs=None, kernel=None):
         self.d = np.matrix([[d]])
         self.u = np.matrix([[u]])
         self.mean = np.matrix(mean).reshape(N, 1) if mean is not None else None
@@ -52,6 +54,26 @@ class RootView:
         kq = topo.knot_rows[topo.knot_ptr[0]:topo.knot_ptr[1]]
         self.kInds = np.sort(topo.perm[kq])
         self.children = []
+        self.locs = locs
+        self._kernel = kernel
+
+    @property
+    def knots(self):
+        return np.asarray(self.locs)[self.kInds]
+
+    @property
+    def B(self):
+        if self._kernel is None:
+            raise AttributeError("root.B needs a device kernel (KernelSpec) to be evaluated lazily")
+        return np.matrix(self._kernel.evaluate(np.asarray(self.locs), self.knots))
+
+    @property
+    def kInv(self):
+        return self.B[self.kInds, :]
+
+    @property
+    def k(self):
+        return np.linalg.inv(self.kInv)
 
 
 def probe_cov(cov, d, locs=None):
@@ -109,7 +131,7 @@ class MRATree(object):
             mean, var = self.plan.predict()
         else:
             mean, var = None, None
-        self.root = RootView(d, u, mean, var, N, self.topology)
+        self.root = RootView(d, u, mean, var, N, self.topology, np.asarray(locs, dtype=np.float64), spec)
 
     def getLikelihood(self):
         return self.root.d + self.root.u
@@ -132,5 +154,5 @@ class MRATree(object):
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()
         mean, var = self.plan.predict() if want_predict else (None, None)
-        self.root = RootView(d, u, mean, var, len(self.locs), self.topology)
+        self.root = RootView(d, u, mean, var, len(self.locs), self.topology, np.asarray(self.locs, dtype=np.float64), spec)
         return self.getLikelihood()

@@ -1187,28 +1187,6 @@ __global__ __launch_bounds__(512) void k_predict_cascade(PredArgs ar) {
     }
 }
 
-// kInv of the nodes of one level from their knots: cov(knots, knots) - Wk Wk^T, identity on phantoms
-template <int DIM>
-__global__ void k_knot_kinv(const double* __restrict__ kx, const int* __restrict__ kvalid, const double* __restrict__ Wk,
-                            double* __restrict__ Lp, int cw, int K, KernelParams kp) {
-    const long node = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= cw * cw) return;
-    const int a = e / cw, b = e % cw;
-    const int* kv = kvalid + node * cw;
-    double v = (a == b) ? 1.0 : 0.0;
-    if (kv[a] && kv[b]) {
-        const double* xa = kx + (node * cw + a) * DIM;
-        const double* xb = kx + (node * cw + b) * DIM;
-        const double* wa = Wk + (node * cw + a) * K;
-        const double* wb = Wk + (node * cw + b) * K;
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s += wa[k] * wb[k];
-        v = cov_of_dist(kp, sqrt(pair_dist2<DIM>(xa, xb, kp.circular))) - s;
-    }
-    Lp[(node * cw + a) * cw + b] = v;
-}
-
 // ------------------------------------------------------------------------------------------------
 //  small kernels
 // ------------------------------------------------------------------------------------------------

@@ -330,3 +330,29 @@ def test_large_fully_observed_leaves(hip):
     d, u = pl.likelihood()
     assert abs(d + u - lik) <= 1e-12 * abs(lik)
     pl.close()
+
+
+def test_not_positive_definite_is_reported(hip):
+    """A numerically singular knot block: the reference drops into pdb (pyMRA/MRANode.py:386-390); here the
+    Cholesky flags the non-positive pivot and the run raises MRA_ERR_NOT_SPD."""
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("c1")
+    cov = lambda a, b: mt.GaussianCovFun(a, b, l=50.0, sig=1.0)      # 16 knots, condition number ~1e60
+    with pytest.raises(hip.MraError) as ei:
+        pymra_amd.MRATree(cs["locs"], 16, cov, cs["y_obs"], 1e-2, M=1, J=3)
+    assert ei.value.code == -3
+
+
+def test_root_view_attributes(hip):
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("g32")
+    c = cs["c"]
+    np.random.seed(7); K.mg.make_inputs(c)
+    tree = pymra_amd.MRATree(cs["locs"], c["r"], lambda a, b: mt.ExpCovFun(a, b, l=c["l"]), cs["y_obs"], c["R"], M=c["M"], J=c["J"])
+    g = cs["g"]
+    assert np.array_equal(tree.root.kInds, g["knots"][g["knot_ptr"][0]:g["knot_ptr"][1]])     # the reference's root knots
+    assert tree.root.knots.shape == (c["r"], 2) and tree.root.B.shape == (len(cs["locs"]), c["r"])
+    assert np.allclose(np.asarray(tree.root.kInv), np.asarray(mt.ExpCovFun(tree.root.knots, tree.root.knots, l=c["l"])))
+    assert abs(tree.root.d[0, 0] - float(g["d"])) <= 1e-8 * abs(float(g["d"])) and abs(tree.root.u[0, 0] - float(g["u"])) <= 1e-8 * abs(float(g["u"]))
