@@ -214,15 +214,24 @@ def main():
         dom_ms = dom["ms"] / max(dom["launches"], 1)
         dom_fl = dom["flops"] / max(dom["launches"], 1)
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        if os.path.exists(tf):
+        # HBM traffic of the dominant kernel from the committed PMC summary of this same command
+        # (tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
+        traffic, traffic_raw, traffic_src = None, None, None
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_by_kernel_family.json")))
+        if cands:
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                fam = json.load(open(cands[-1])).get(dom["name"])
+                if fam:
+                    traffic = fam.get("hbm_bytes_per_launch")
+                    traffic_raw = {"FETCH_SIZE_KB": fam.get("FETCH_SIZE_KB_per_launch_mean"),
+                                   "WRITE_SIZE_KB": fam.get("WRITE_SIZE_KB_per_launch_mean")}
+                    traffic_src = os.path.basename(cands[-1])
             except Exception:
-                traffic = None
+                pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_raw_counters": traffic_raw, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_ms, "flop_per_launch": dom_fl,
                 "kernels": [{"name": k["name"], "launches_per_step": k["launches"] / args.steps,
                              "ms_per_step": k["ms"] / args.steps,
