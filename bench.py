@@ -38,6 +38,8 @@ HBM_PEAK_GBS = 8000.0
 CONFIGS = {
     "c3": dict(n=1024, M=6, J=4, r=32, kern="m32", l=0.3, sig=1.0, R=1e-2, seed=11, frac=0.4),
     "c2": dict(n=256, M=4, J=4, r=16, kern="exp", l=0.3, sig=1.0, R=1e-2, seed=11, frac=0.4),
+    # BASELINE.json config 5 geometry (general level-by-level kernels; 29 GB on one GPU)
+    "c5": dict(n=2048, M=8, J=4, r=64, kern="m32", l=0.3, sig=1.0, R=1e-2, seed=11, frac=0.4),
 }
 
 

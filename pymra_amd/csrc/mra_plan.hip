@@ -159,6 +159,10 @@ struct mra_plan {
     DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
     DevVec<GemmSeg> parentSegs;
     bool parent_syrk = false, direct_parent = false;
+    bool shape_regular = false;          // every leaf sits on the last level (all other levels hold non-leaf nodes only)
+    std::vector<AsmChild> hKids;         // host copies: the leaves' Gt blocks are allocated only when something needs them
+    std::vector<int> kid_leaf;
+    std::vector<GemmProb> hLeafSyrk;
     int leaf_max_tiles_full = 0, leaf_max_tiles_lik = 0;
     DevVec<AsmChild> asmKids;
     long leaf_max_rows = 0;
@@ -299,10 +303,22 @@ static void build_static(mra_plan* pl) {
         const int na = pl->na[pl->node_level[pl->leaf_nodes[t]]];
         pl->leaf_goff[t + 1] = pl->leaf_goff[t] + (long)na * na;
     }
-    pl->Gt.alloc(pl->leaf_goff.back());
+    {
+        const int Lq = pl->n_levels;
+        bool ok = Lq >= 2;
+        for (int m = 0; m < Lq - 1 && ok; ++m)
+            for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1] && ok; ++i) if (pl->leaf[i]) ok = false;
+        for (long i = pl->level_ptr[Lq - 1]; i < pl->level_ptr[Lq] && ok; ++i) if (!pl->leaf[i]) ok = false;
+        pl->shape_regular = ok;
+        if (ok) pl->NL = Lq - 1;
+    }
+    // shape-regular trees build the leaves' parents straight from the children's Ut blocks (segmented SYRK),
+    // so the per-leaf Schur blocks Gt (146 GB at 2048^2, M=8, r0=64) are only allocated on demand (ensure_gt)
+    if (!pl->shape_regular) pl->Gt.alloc(pl->leaf_goff.back());
 
     // descriptors that do not depend on the observations
     std::vector<AsmChild> kids;
+    pl->kid_leaf.clear();
     for (int m = 0; m < L; ++m) {
         LevelData& lv = pl->lev[m];
         const size_t nn = lv.nodes.size();
@@ -363,7 +379,8 @@ static void build_static(mra_plan* pl) {
                 const int ch = pl->child_list[c];
                 if (pl->node_level[ch] != m + 1) throw MraError(MRA_ERR_INVALID, "child must be one level below its parent");
                 AsmChild k{};
-                if (pl->leaf[ch]) { k.G = pl->Gt.p + pl->leaf_goff[pl->leaf_slot[ch]]; k.ld = pl->na[m + 1]; }
+                pl->kid_leaf.push_back(pl->leaf[ch] ? pl->leaf_slot[ch] : -1);
+                if (pl->leaf[ch]) { k.G = pl->Gt.p ? pl->Gt.p + pl->leaf_goff[pl->leaf_slot[ch]] : nullptr; k.ld = pl->na[m + 1]; }
                 else {
                     const LevelData& cl = pl->lev[m + 1];
                     k.G = cl.F.p + (size_t)pl->node_slot[ch] * cl.nf * cl.nf + (size_t)cl.cw * cl.nf + cl.cw;
@@ -383,6 +400,7 @@ static void build_static(mra_plan* pl) {
         lv.tile_node.upload(tnode); lv.tile_row0.upload(trow);
     }
     pl->asmKids.upload(kids);
+    pl->hKids = kids;
 
     // ---- fused path eligibility: uniform block width on all non-leaf levels, leaves only on the last level
     pl->regular = false;
@@ -561,7 +579,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->fl_leaf_chol_lik += (double)nop * nop * nop / 3.0 + (double)na * nop * nop;
         GemmProb s{};
         s.A = Pn + (size_t)nop * nop; s.lda = nop; s.B = s.A; s.ldb = nop;
-        s.C = pl->Gt.p + pl->leaf_goff[t]; s.ldc = na; s.M = na; s.N = na; s.K = nop; s.lower = 1;
+        s.C = pl->Gt.p ? pl->Gt.p + pl->leaf_goff[t] : nullptr; s.ldc = na; s.M = na; s.N = na; s.K = nop; s.lower = 1;
         gs[t] = s;
         pl->fl_leaf_syrk += (double)na * na * nop;
         GemmProb u{};
@@ -580,7 +598,8 @@ static void build_leaf(mra_plan* pl, const double* y) {
         if (pl->panel.n) HIP_TRY(hipMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
     }
     pl->parent_syrk = false;
-    if (pl->regular && pl->NL >= 1) {
+    pl->hLeafSyrk = gs;
+    if (pl->shape_regular && pl->NL >= 1) {
         const LevelData& lv = pl->lev[pl->NL - 1];
         std::vector<GemmProb> ps(lv.nodes.size());
         std::vector<GemmSeg> segs;
@@ -959,6 +978,17 @@ static void finish_run(mra_plan* pl) {
     }
 }
 
+// allocate the per-leaf Schur blocks the first time a run needs them and point the descriptors at them
+static void ensure_gt(mra_plan* pl) {
+    if (pl->Gt.p || pl->leaf_goff.back() == 0) return;
+    pl->Gt.alloc(pl->leaf_goff.back());
+    for (size_t k = 0; k < pl->hKids.size(); ++k)
+        if (pl->kid_leaf[k] >= 0) pl->hKids[k].G = pl->Gt.p + pl->leaf_goff[pl->kid_leaf[k]];
+    pl->asmKids.upload(pl->hKids);
+    for (size_t t = 0; t < pl->hLeafSyrk.size(); ++t) pl->hLeafSyrk[t].C = pl->Gt.p + pl->leaf_goff[t];
+    pl->gLeafSyrk.upload(pl->hLeafSyrk);
+}
+
 static void run_all(mra_plan* pl, uint32_t flags) {
     if (!(pl->have_locs && pl->have_obs && pl->have_kernel))
         throw MraError(MRA_ERR_STATE, "mra_run needs set_locs, set_obs and set_kernel first");
@@ -1042,7 +1072,8 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
             }
         }
-        pl->direct_parent = fused && pl->parent_syrk && pl->reduce_level != pl->NL - 1;
+        pl->direct_parent = pl->parent_syrk && pl->reduce_level != pl->NL - 1;
+        if (!pl->direct_parent) ensure_gt(pl);
         if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false); }
         if (pred) {
             if (!fused || pl->leaf_max_nop / 16 > 12) {
