@@ -71,10 +71,19 @@ def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
             level = m
     top = int(topo.level_ptr[level])
     n, secs, tm = run_subtree_sample(topo, locs, cov, y_obs, c["R"], top, do_gc=True)
+    # threads actually used: the BLAS/LAPACK pool NumPy and SciPy run on (the Python loop itself is serial)
+    cores = None
     try:
-        cores = len(os.sched_getaffinity(0))
+        from threadpoolctl import threadpool_info
+        pools = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        cores = max(pools) if pools else None
     except Exception:
-        cores = os.cpu_count()
+        pass
+    if not cores:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            cores = os.cpu_count()
     return {"value": n / secs, "unit": "nodes/s", "cores": cores, "kind": "port",
             "sample": "subtree of level-%d node %d of the same tree: %d nodes (%.1f s; prior %.1f s, posterior %.1f s, "
                       "per-node gc.collect %.1f s as in MRANode.py:111), NumPy/SciPy default BLAS threads"
