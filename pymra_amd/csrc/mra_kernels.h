@@ -293,36 +293,81 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
     const d4 zero = {0, 0, 0, 0};
     d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
     const int nk = pb.K >> 4;
-    d4 ra = zero, rb = zero;
+    // register prefetch two K-steps ahead (two register sets, statically indexed by unrolling by 2),
+    // LDS double-buffered: the global load of step k+2 is in flight during the whole of step k
+    d4 ra0 = zero, rb0 = zero, ra1 = zero, rb1 = zero;
     if (nk > 0) {
-        ra = a_ok ? *(const d4*)ap : zero;
-        rb = b_ok ? *(const d4*)bp : zero;
-        *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra;
-        *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb;
+        ra0 = a_ok ? *(const d4*)ap : zero;
+        rb0 = b_ok ? *(const d4*)bp : zero;
+        *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra0;
+        *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb0;
+    }
+    if (nk > 1) {
+        ra1 = a_ok ? *(const d4*)(ap + 16) : zero;
+        rb1 = b_ok ? *(const d4*)(bp + 16) : zero;
     }
     __syncthreads();
     const int arow0 = (wm * 32 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
     const int brow0 = (wn * 32 + r) * GL_LDS_LD + 4 * q, brow1 = brow0 + 16 * GL_LDS_LD;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) {
-            ra = a_ok ? *(const d4*)(ap + (ks + 1) * 16) : zero;
-            rb = b_ok ? *(const d4*)(bp + (ks + 1) * 16) : zero;
-        }
-        const d4 a0 = *(const d4*)(&sA[cur][arow0]);
-        const d4 a1 = *(const d4*)(&sA[cur][arow1]);
-        const d4 b0 = *(const d4*)(&sB[cur][brow0]);
-        const d4 b1 = *(const d4*)(&sB[cur][brow1]);
+    // which of this wave's four 16x16 sub-tiles exist (wave-uniform): padded sub-tiles issue no MFMA
+    const bool w_m0 = (M0 + wm * 32) < pb.M, w_m1 = (M0 + wm * 32 + 16) < pb.M;
+    const bool w_n0 = (N0 + wn * 32) < pb.N, w_n1 = (N0 + wn * 32 + 16) < pb.N;
+    auto compute = [&](int cur) {
+        if (w_m0 && w_n0) {
+            const d4 a0 = *(const d4*)(&sA[cur][arow0]);
+            const d4 b0 = *(const d4*)(&sB[cur][brow0]);
+            if (w_m1 && w_n1) {
+                const d4 a1 = *(const d4*)(&sA[cur][arow1]);
+                const d4 b1 = *(const d4*)(&sB[cur][brow1]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            c00 = mfma16(a0[j], b0[j], c00);
-            c01 = mfma16(a0[j], b1[j], c01);
-            c10 = mfma16(a1[j], b0[j], c10);
-            c11 = mfma16(a1[j], b1[j], c11);
+                for (int j = 0; j < 4; ++j) {
+                    c00 = mfma16(a0[j], b0[j], c00);
+                    c01 = mfma16(a0[j], b1[j], c01);
+                    c10 = mfma16(a1[j], b0[j], c10);
+                    c11 = mfma16(a1[j], b1[j], c11);
+                }
+            } else if (w_m1) {
+                const d4 a1 = *(const d4*)(&sA[cur][arow1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c00 = mfma16(a0[j], b0[j], c00);
+                    c10 = mfma16(a1[j], b0[j], c10);
+                }
+            } else if (w_n1) {
+                const d4 b1 = *(const d4*)(&sB[cur][brow1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c00 = mfma16(a0[j], b0[j], c00);
+                    c01 = mfma16(a0[j], b1[j], c01);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c00 = mfma16(a0[j], b0[j], c00);
+            }
         }
+    };
+    for (int ks = 0; ks < nk; ks += 2) {
+        // ---- even step: LDS buffer 0 holds step ks; registers set 1 holds step ks+1; fetch ks+2 into set 0
+        if (ks + 2 < nk) {
+            ra0 = a_ok ? *(const d4*)(ap + (ks + 2) * 16) : zero;
+            rb0 = b_ok ? *(const d4*)(bp + (ks + 2) * 16) : zero;
+        }
+        compute(0);
         if (ks + 1 < nk) {
-            *(d4*)(&sA[cur ^ 1][srow * GL_LDS_LD + sch]) = ra;
-            *(d4*)(&sB[cur ^ 1][srow * GL_LDS_LD + sch]) = rb;
+            *(d4*)(&sA[1][srow * GL_LDS_LD + sch]) = ra1;
+            *(d4*)(&sB[1][srow * GL_LDS_LD + sch]) = rb1;
+        }
+        __syncthreads();
+        if (ks + 1 >= nk) break;
+        // ---- odd step: LDS buffer 1 holds step ks+1; registers set 0 holds step ks+2; fetch ks+3 into set 1
+        if (ks + 3 < nk) {
+            ra1 = a_ok ? *(const d4*)(ap + (ks + 3) * 16) : zero;
+            rb1 = b_ok ? *(const d4*)(bp + (ks + 3) * 16) : zero;
+        }
+        compute(1);
+        if (ks + 2 < nk) {
+            *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra0;
+            *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb0;
         }
         __syncthreads();
     }
