@@ -356,3 +356,25 @@ def test_root_view_attributes(hip):
     assert tree.root.knots.shape == (c["r"], 2) and tree.root.B.shape == (len(cs["locs"]), c["r"])
     assert np.allclose(np.asarray(tree.root.kInv), np.asarray(mt.ExpCovFun(tree.root.knots, tree.root.knots, l=c["l"])))
     assert abs(tree.root.d[0, 0] - float(g["d"])) <= 1e-8 * abs(float(g["d"])) and abs(tree.root.u[0, 0] - float(g["u"])) <= 1e-8 * abs(float(g["u"]))
+
+
+def test_plan_reuse_for_mle(hip):
+    """MLE loops (README.md:96-104) re-evaluate the likelihood for new kernel parameters on the SAME tree:
+    `reevaluate` must equal a fresh MRATree built with the same seed."""
+    import pymra_amd
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("g64m")
+    c = cs["c"]
+
+    def fresh(kappa, sig):
+        np.random.seed(c["seed"]); K.mg.make_inputs(c)          # RNG where the recipe leaves it: same knots
+        return pymra_amd.MRATree(cs["locs"], c["r"], lambda a, b: sig * mt.Matern32(a, b, l=kappa), cs["y_obs"], c["R"],
+                                 M=c["M"], J=c["J"])
+    base = fresh(0.3, 1.0)
+    for kappa, sig in ((0.2, 1.0), (0.45, 1.7)):
+        lik = base.reevaluate(lambda a, b: sig * mt.Matern32(a, b, l=kappa))
+        ref = fresh(kappa, sig)
+        assert isinstance(lik, np.matrix) and abs(lik[0, 0] - ref.getLikelihood()[0, 0]) <= 1e-12 * abs(ref.getLikelihood()[0, 0])
+    full = base.reevaluate(lambda a, b: mt.Matern32(a, b, l=0.3, sig=1.0), want_predict=True)
+    assert abs(full[0, 0] - float(cs["g"]["lik"])) <= 1e-9 * abs(float(cs["g"]["lik"]))
+    assert np.max(np.abs(np.asarray(base.predict()[0]).ravel() - cs["g"]["mean"])) < 1e-7
