@@ -145,6 +145,24 @@ int mra_get_kernel_stats(mra_plan *plan, int which, char *name, int name_cap, in
 /* out[0..7] = P, ldw, Ka, n_leaves, bytes(W), bytes(leaf panels), bytes(leaf Gt), n_nodes */
 int mra_plan_info(mra_plan *plan, int64_t *out, int capacity);
 
+/* ---- native host tree replay (no GPU involved) -------------------------------------------------------
+ * Replaces, for large 2-D trees (every node above the leaves has > 100 rows and > 100 candidates, J = 4): the
+ * knot selection and partition part of Node.__init__ (pyMRA/MRANode.py:34-59, 191-193, 232-239) and the flat
+ * layout of pymra_amd.topology.  mt_key[624] / mt_pos are NumPy's global MT19937 state
+ * (np.random.get_state()[1:3]); on success they hold the state after the reference's knot draws.
+ * Returns 0, or 1 when the tree does not follow those rules (state untouched; use the Python replay). */
+typedef struct mra_tree mra_tree;
+int mra_tree_replay_2d(const double *locs, int64_t N, int32_t r, int32_t M, uint32_t *mt_key, int32_t *mt_pos,
+                       mra_tree **out);
+/* out5 = {P, n_nodes, n_levels, len(child_list), len(knot_rows)} */
+int mra_tree_sizes(mra_tree *t, int64_t *out5);
+/* copies the arrays of `mra_topology` (+ perm, src, in_leaf, node_level, pre-order) into caller buffers */
+int mra_tree_export(mra_tree *t, int64_t *perm, int64_t *src, uint8_t *in_leaf, int64_t *level_ptr,
+                    int32_t *node_level, int64_t *row0, int64_t *row1, uint8_t *leaf, int32_t *parent,
+                    int32_t *child_ptr, int32_t *child_list, int64_t *knot_ptr, int64_t *knot_rows, int32_t *cw,
+                    int32_t *preorder);
+int mra_tree_free(mra_tree *t);
+
 /* ---- multi-GPU: one process per GPU, subtrees sharded, ONE all-reduce of the shard-level fronts --
  * The reference's only parallel mode forks one process per child subtree at `critDepth` and pickles
  * the finished Node back (pyMRA/MRANode.py:64-65, 90-104, 114-115); here each rank owns whole

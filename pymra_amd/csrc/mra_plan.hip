@@ -9,6 +9,7 @@
 //   4. predictive moments, bottom-up(:486-520)
 // DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
 #include "mra_kernels.h"
+#include "mra_topology.h"
 #include "../../include/mra_hip.h"
 
 #include <algorithm>
@@ -1392,6 +1393,42 @@ int mra_eval_kernel(int kind, const double* params, int n_params, const double* 
     if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return MRA_ERR_HIP; }
     return MRA_OK;
 }
+
+// ---- native tree replay (host only, no GPU needed) ---------------------------------------------------
+struct mra_tree { mra_topo::Result r; };
+
+int mra_tree_replay_2d(const double* locs, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, mra_tree** out) {
+    if (!locs || !mt_key || !mt_pos || !out) return MRA_ERR_INVALID;
+    *out = nullptr;
+    mra_tree* t = new mra_tree();
+    int rc;
+    try { rc = mra_topo::replay_quadtree(locs, N, r, M, mt_key, mt_pos, t->r); }
+    catch (const std::exception& e) { g_last_error = e.what(); delete t; return MRA_ERR_INVALID; }
+    if (rc != 0) { delete t; return 1; }
+    *out = t;
+    return MRA_OK;
+}
+
+int mra_tree_sizes(mra_tree* t, int64_t* out5) {
+    if (!t || !out5) return MRA_ERR_INVALID;
+    out5[0] = t->r.P; out5[1] = t->r.n_nodes; out5[2] = t->r.n_levels;
+    out5[3] = (int64_t)t->r.child_list.size(); out5[4] = (int64_t)t->r.knot_rows.size();
+    return MRA_OK;
+}
+
+int mra_tree_export(mra_tree* t, int64_t* perm, int64_t* src, uint8_t* in_leaf, int64_t* level_ptr, int32_t* node_level,
+                    int64_t* row0, int64_t* row1, uint8_t* leaf, int32_t* parent, int32_t* child_ptr, int32_t* child_list,
+                    int64_t* knot_ptr, int64_t* knot_rows, int32_t* cw, int32_t* preorder) {
+    if (!t) return MRA_ERR_INVALID;
+    const mra_topo::Result& r = t->r;
+    auto cp = [](auto* dst, const auto& v) { if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+    cp(perm, r.perm); cp(src, r.src); cp(in_leaf, r.in_leaf); cp(level_ptr, r.level_ptr); cp(node_level, r.level);
+    cp(row0, r.row0); cp(row1, r.row1); cp(leaf, r.leaf); cp(parent, r.parent); cp(child_ptr, r.child_ptr);
+    cp(child_list, r.child_list); cp(knot_ptr, r.knot_ptr); cp(knot_rows, r.knot_rows); cp(cw, r.cw); cp(preorder, r.preorder);
+    return MRA_OK;
+}
+
+int mra_tree_free(mra_tree* t) { delete t; return MRA_OK; }
 
 // ---- multi-GPU ------------------------------------------------------------------------------------
 int mra_plan_set_reduce_level(mra_plan* pl, int level) {

@@ -1,0 +1,221 @@
+// mra_topology.h - native replay of pyMRA's tree construction for the common large 2-D case.
+//
+// What it replays (same rules as pymra_amd/topology.py, which stays the general implementation and the
+// fallback):
+//   * quadrant partition about the coordinate means of every node with more than 100 rows
+//     (pyMRA/MRANode.py:232-239; np.mean(locs, axis=0) is a sequential row accumulation - reproduced here
+//     bit for bit, because rows that sit exactly on a mean change child otherwise),
+//   * knots of every non-leaf node: np.random.choice(arange(n_cand), size=r, replace=False) on NumPy's
+//     GLOBAL legacy RandomState, in depth-first pre-order (pyMRA/MRANode.py:191-193).  That call is
+//     permutation(n)[:r], i.e. a Fisher-Yates shuffle of arange(n) driven by MT19937 through
+//     random_interval() (masked rejection sampling on 32-bit draws).  The caller hands over the MT19937
+//     key/pos of np.random.get_state() and writes the advanced state back with np.random.set_state(),
+//   * leaves: every not-yet-used row of the leaf is a knot (pyMRA/MRANode.py:42-45),
+//   * the padded, leaf-ordered flat layout of pymra_amd.topology.Topology.
+// Not applicable (returns 1, state untouched): a node above the leaves with <= 100 rows or
+// <= max(100, r, 4) candidates, or an empty quadrant - those follow other rules in the reference
+// (KMeans knots / splits) and are handled by the Python replay.
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include <vector>
+
+namespace mra_topo {
+
+struct MT19937 {
+    uint32_t* key;
+    int pos;
+    inline void regenerate() {
+        const uint32_t MATRIX_A = 0x9908b0dfU, UPPER = 0x80000000U, LOWER = 0x7fffffffU;
+        int kk;
+        uint32_t y;
+        for (kk = 0; kk < 624 - 397; ++kk) {
+            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+        }
+        for (; kk < 623; ++kk) {
+            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
+            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+        }
+        y = (key[623] & UPPER) | (key[0] & LOWER);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+        pos = 0;
+    }
+    inline uint32_t next32() {
+        if (pos == 624) regenerate();
+        uint32_t y = key[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680U;
+        y ^= (y << 15) & 0xefc60000U;
+        y ^= (y >> 18);
+        return y;
+    }
+    // numpy/random/src/distributions: random_interval(max), max <= 0xffffffff
+    inline uint64_t interval(uint64_t max) {
+        if (max == 0) return 0;
+        uint64_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        uint64_t v;
+        if (max <= 0xffffffffULL) {
+            while ((v = (next32() & mask)) > max) {}
+        } else {
+            while ((v = ((((uint64_t)next32()) << 32) | next32()) & mask) > max) {}
+        }
+        return v;
+    }
+};
+
+struct Result {
+    int64_t P = 0;
+    int32_t n_nodes = 0, n_levels = 0;
+    std::vector<int64_t> perm, src, level_ptr, row0, row1, knot_ptr, knot_rows;
+    std::vector<uint8_t> in_leaf, leaf;
+    std::vector<int32_t> parent, child_ptr, child_list, level, preorder, cw;
+};
+
+// returns 0 on success, 1 if the tree does not follow the large-2-D rules (nothing modified)
+inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out) {
+    if (M < 1 || N <= 0 || r <= 0) return 1;
+    // ---- partitions of all levels (they do not depend on the knots)
+    std::vector<std::vector<int64_t>> orders(M + 1), starts(M + 1);
+    orders[0].resize(N);
+    for (int64_t i = 0; i < N; ++i) orders[0][i] = i;
+    starts[0] = {0, N};
+    for (int m = 0; m < M; ++m) {
+        const std::vector<int64_t>& ord = orders[m];
+        const std::vector<int64_t>& st = starts[m];
+        const int64_t nn = (int64_t)st.size() - 1;
+        orders[m + 1].resize(N);
+        starts[m + 1].assign(4 * nn + 1, 0);
+        std::vector<int64_t>& nxt = orders[m + 1];
+        std::vector<int64_t>& nst = starts[m + 1];
+        for (int64_t j = 0; j < nn; ++j) {
+            const int64_t s = st[j], e = st[j + 1], n = e - s;
+            if (n <= 100) return 1;
+            double sx = 0.0, sy = 0.0;                       // np.mean(axis=0): sequential accumulation, then / n
+            for (int64_t t = s; t < e; ++t) { sx += xy[2 * ord[t]]; sy += xy[2 * ord[t] + 1]; }
+            const double mx = sx / (double)n, my = sy / (double)n;
+            int64_t cnt[4] = {0, 0, 0, 0};
+            for (int64_t t = s; t < e; ++t) {
+                const int c = 2 * (xy[2 * ord[t]] > mx) + (xy[2 * ord[t] + 1] > my);
+                ++cnt[c];
+            }
+            if (!cnt[0] || !cnt[1] || !cnt[2] || !cnt[3]) return 1;
+            int64_t off[4];
+            off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
+            for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
+            for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
+                const int c = 2 * (xy[2 * ord[t]] > mx) + (xy[2 * ord[t] + 1] > my);
+                nxt[off[c]++] = ord[t];
+            }
+        }
+        nst[4 * nn] = N;
+    }
+    // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
+    uint32_t key[624];
+    for (int i = 0; i < 624; ++i) key[i] = mt_key[i];
+    MT19937 rng{key, *mt_pos};
+    std::vector<uint8_t> used(N, 0);
+    std::vector<std::vector<int64_t>> knots(M);                // per level: r knots per node, node-major
+    for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
+    std::vector<int64_t> cand, perm_idx;
+    std::vector<std::pair<int, int64_t>> stack;
+    stack.push_back({0, 0});
+    const int64_t min_cand = std::max<int64_t>(100, std::max<int64_t>(r, 4));
+    while (!stack.empty()) {
+        const int m = stack.back().first;
+        const int64_t j = stack.back().second;
+        stack.pop_back();
+        const int64_t s = starts[m][j], e = starts[m][j + 1];
+        cand.clear();
+        for (int64_t t = s; t < e; ++t) if (!used[orders[m][t]]) cand.push_back(orders[m][t]);
+        const int64_t nc = (int64_t)cand.size();
+        if (nc <= min_cand) return 1;
+        perm_idx.resize(nc);
+        for (int64_t i = 0; i < nc; ++i) perm_idx[i] = i;
+        for (int64_t i = nc - 1; i >= 1; --i) {               // RandomState.shuffle: _shuffle_raw
+            const int64_t k = (int64_t)rng.interval((uint64_t)i);
+            std::swap(perm_idx[i], perm_idx[k]);
+        }
+        int64_t* kn = knots[m].data() + j * r;
+        for (int i = 0; i < r; ++i) kn[i] = cand[perm_idx[i]];
+        std::sort(kn, kn + r);
+        for (int i = 0; i < r; ++i) used[kn[i]] = 1;
+        if (m + 1 < M) for (int c = 3; c >= 0; --c) stack.push_back({m + 1, 4 * j + c});
+    }
+    // ---- flat layout
+    const int L = M + 1;
+    out.n_levels = L;
+    out.level_ptr.assign(L + 1, 0);
+    for (int m = 0; m < L; ++m) out.level_ptr[m + 1] = out.level_ptr[m] + ((int64_t)1 << (2 * m));
+    const int64_t nn = out.level_ptr[L];
+    out.n_nodes = (int32_t)nn;
+    const int64_t nleaf = (int64_t)1 << (2 * M);
+    std::vector<int64_t> leaf_off(nleaf + 1, 0);
+    for (int64_t l = 0; l < nleaf; ++l) {
+        const int64_t c = starts[M][l + 1] - starts[M][l];
+        leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
+    }
+    out.P = leaf_off[nleaf];
+    out.perm.assign(out.P, -1);
+    out.src.assign(out.P, 0);
+    out.in_leaf.assign(out.P, 0);
+    std::vector<int64_t> pos_of(N, -1);
+    const std::vector<int64_t>& oM = orders[M];
+    for (int64_t l = 0; l < nleaf; ++l) {
+        const int64_t s = starts[M][l], e = starts[M][l + 1];
+        int64_t p = leaf_off[l];
+        for (int64_t t = s; t < e; ++t, ++p) { out.perm[p] = oM[t]; out.src[p] = oM[t]; out.in_leaf[p] = 1; pos_of[oM[t]] = p; }
+        for (; p < leaf_off[l + 1]; ++p) out.src[p] = oM[s];      // phantom rows copy the leaf's first location
+    }
+    out.level.assign(nn, 0); out.row0.assign(nn, 0); out.row1.assign(nn, 0); out.leaf.assign(nn, 0);
+    out.parent.assign(nn, -1); out.child_ptr.assign(nn + 1, 0);
+    out.child_list.clear();
+    out.knot_ptr.assign(nn + 1, 0);
+    out.knot_rows.clear();
+    out.knot_rows.reserve(N);
+    for (int m = 0; m < L; ++m) {
+        const int64_t span = (int64_t)1 << (2 * (M - m));
+        for (int64_t j = 0; j < ((int64_t)1 << (2 * m)); ++j) {
+            const int64_t i = out.level_ptr[m] + j;
+            out.level[i] = m;
+            out.row0[i] = leaf_off[j * span];
+            out.row1[i] = leaf_off[(j + 1) * span];
+            out.leaf[i] = (m == M);
+            out.parent[i] = m ? (int32_t)(out.level_ptr[m - 1] + j / 4) : -1;
+            if (m < M) {
+                for (int c = 0; c < 4; ++c) out.child_list.push_back((int32_t)(out.level_ptr[m + 1] + 4 * j + c));
+                const int64_t* kn = knots[m].data() + j * r;
+                for (int t = 0; t < r; ++t) out.knot_rows.push_back(pos_of[kn[t]]);
+            } else {
+                const int64_t s = starts[M][j], e = starts[M][j + 1];
+                for (int64_t t = s; t < e; ++t) if (!used[oM[t]]) out.knot_rows.push_back(pos_of[oM[t]]);
+            }
+            out.child_ptr[i + 1] = (int32_t)out.child_list.size();
+            out.knot_ptr[i + 1] = (int64_t)out.knot_rows.size();
+        }
+    }
+    out.cw.assign(L, 0);
+    for (int m = 0; m < M; ++m) out.cw[m] = (r + 15) / 16 * 16;
+    out.preorder.clear();
+    out.preorder.reserve(nn);
+    {
+        std::vector<int64_t> st2;
+        st2.push_back(0);
+        while (!st2.empty()) {
+            const int64_t i = st2.back();
+            st2.pop_back();
+            out.preorder.push_back((int32_t)i);
+            if (!out.leaf[i]) {
+                const int m = out.level[i];
+                const int64_t c0 = out.level_ptr[m + 1] + 4 * (i - out.level_ptr[m]);
+                for (int c = 3; c >= 0; --c) st2.push_back(c0 + c);
+            }
+        }
+    }
+    for (int i = 0; i < 624; ++i) mt_key[i] = key[i];
+    *mt_pos = rng.pos;
+    return 0;
+}
+
+}  // namespace mra_topo

@@ -30,6 +30,7 @@ EXPORTS = [
     "mra_get_kernel_stats", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
     "mra_run_resume", "mra_last_error", "mra_version",
+    "mra_tree_replay_2d", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
 ]
 
 
@@ -85,6 +86,10 @@ def load_library():
         "mra_reduce_size": (C.c_int, [vp, C.POINTER(i64)]),
         "mra_reduce_export": (C.c_int, [vp, vp]),
         "mra_reduce_import": (C.c_int, [vp, vp]),
+        "mra_tree_replay_2d": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(vp)]),
+        "mra_tree_sizes": (C.c_int, [vp, vp]),
+        "mra_tree_export": (C.c_int, [vp] + [vp] * 15),
+        "mra_tree_free": (C.c_int, [vp]),
         "mra_last_error": (C.c_char_p, [vp]),
         "mra_version": (C.c_char_p, []),
     }

@@ -252,7 +252,57 @@ class Topology:
         return np.diff(self.level_ptr)
 
 
-def build_topology(locs: np.ndarray, r: int, M: int, J: int) -> Topology:
+def _replay_native(coords: np.ndarray, r: int, M: int, J: int) -> Optional[Topology]:
+    """Large 2-D trees: the replay runs in libmra_hip.so (csrc/mra_topology.h; host code, no GPU needed),
+    driven by and returning NumPy's global MT19937 state.  None when the library is not built or the tree
+    does not follow the large-2-D rules (then the Python replay below does the job; results are identical,
+    tests/test_topology.py)."""
+    if coords.shape[1] != 2 or J != 4 or M < 1:
+        return None
+    try:
+        import ctypes as C
+        from .plan import load_library
+        lib = load_library()
+    except Exception:
+        return None
+    state = np.random.get_state()
+    if state[0] != "MT19937":
+        return None
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(state[2]))
+    handle = C.c_void_p()
+    xy = np.ascontiguousarray(coords, dtype=np.float64)
+    rc = lib.mra_tree_replay_2d(xy.ctypes.data_as(C.c_void_p), len(xy), int(r), int(M),
+                                key.ctypes.data_as(C.c_void_p), C.byref(pos), C.byref(handle))
+    if rc != 0:
+        return None
+    try:
+        sz = np.zeros(5, dtype=np.int64)
+        lib.mra_tree_sizes(handle, sz.ctypes.data_as(C.c_void_p))
+        P, n_nodes, n_levels, n_child, n_knots = (int(v) for v in sz)
+        a = dict(perm=np.empty(P, np.int64), src=np.empty(P, np.int64), in_leaf=np.empty(P, np.uint8),
+                 level_ptr=np.empty(n_levels + 1, np.int64), node_level=np.empty(n_nodes, np.int32),
+                 row0=np.empty(n_nodes, np.int64), row1=np.empty(n_nodes, np.int64), leaf=np.empty(n_nodes, np.uint8),
+                 parent=np.empty(n_nodes, np.int32), child_ptr=np.empty(n_nodes + 1, np.int32),
+                 child_list=np.empty(n_child, np.int32), knot_ptr=np.empty(n_nodes + 1, np.int64),
+                 knot_rows=np.empty(n_knots, np.int64), cw=np.empty(n_levels, np.int32), pre=np.empty(n_nodes, np.int32))
+        lib.mra_tree_export(handle, *[v.ctypes.data_as(C.c_void_p) for v in a.values()])
+    finally:
+        lib.mra_tree_free(handle)
+    np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    idents = [""] * n_nodes
+    idents[0] = "r"
+    lp = a["level_ptr"]
+    for i in range(1, n_nodes):
+        idents[i] = idents[a["parent"][i]] + str(int((i - lp[a["node_level"][i]]) % 4) + 1)
+    return Topology(N=len(xy), d=2, M=M, J=J, r=r, P=P, perm=a["perm"], src=a["src"], in_leaf=a["in_leaf"].astype(bool),
+                    n_nodes=n_nodes, n_levels=n_levels, level_ptr=a["level_ptr"], node_level=a["node_level"],
+                    node_row0=a["row0"], node_row1=a["row1"], node_leaf=a["leaf"].astype(bool), node_parent=a["parent"],
+                    child_ptr=a["child_ptr"], child_list=a["child_list"], knot_ptr=a["knot_ptr"], knot_rows=a["knot_rows"],
+                    node_ident=idents, cw=a["cw"], order_preorder=a["pre"])
+
+
+def build_topology(locs: np.ndarray, r: int, M: int, J: int, native: bool = True) -> Topology:
     """Replay the reference's tree construction for ``locs`` (N x d, d in {1,2}).
 
     M and J must already be resolved (``resolve_tree_shape``).  Consumes the global NumPy
@@ -262,6 +312,10 @@ def build_topology(locs: np.ndarray, r: int, M: int, J: int) -> Topology:
     if coords.ndim == 1:
         coords = coords.reshape(-1, 1)
     N, d = coords.shape
+    if native:
+        topo = _replay_native(coords, r, M, J)
+        if topo is not None:
+            return topo
     flat: List[_TNode] = []
     all_rows = np.arange(N, dtype=np.int64)
     import sys

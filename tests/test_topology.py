@@ -47,3 +47,29 @@ def test_shape_resolution_matches_reference_rules():
         resolve_tree_shape(100, 1, 2, 3, -1)                            # MRATree.py:31-33
     with pytest.raises(OverflowError):
         resolve_tree_shape(2, 1, 2, 0, 1)                               # J=1 -> log(J)=0 (unit-tests.py #1)
+
+
+@pytest.mark.parametrize("n,r,M,grid", [(64, 16, 2, True), (129, 16, 2, True), (301, 16, 3, True), (256, 16, 4, True),
+                                         (100, 8, 2, False), (40, 16, 3, True)])
+def test_native_replay_equals_python_replay(built_library, n, r, M, grid):
+    """csrc/mra_topology.h (C++: exact sequential means, MT19937 + NumPy's legacy shuffle) against the general
+    Python replay: every array identical, and NumPy's global RNG left in the same state (also when the
+    native path declines - (40,16,3) has nodes with <= 100 rows - and the Python replay takes over)."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology, _replay_native
+    locs = mt.genLocations2d(Nx=n, Ny=n) if grid else np.random.RandomState(1).uniform(size=(n * n, 2))
+    np.random.seed(5); np.random.normal(size=3)             # leaves a cached Gaussian in the state
+    a = build_topology(locs, r, M, 4, native=True)
+    sa = np.random.get_state()
+    np.random.seed(5); np.random.normal(size=3)
+    b = build_topology(locs, r, M, 4, native=False)
+    sb = np.random.get_state()
+    for f in ("N", "d", "M", "J", "r", "P", "n_nodes", "n_levels", "node_ident"):
+        assert getattr(a, f) == getattr(b, f), f
+    for f in ("perm", "src", "in_leaf", "level_ptr", "node_level", "node_row0", "node_row1", "node_leaf", "node_parent",
+              "child_ptr", "child_list", "knot_ptr", "knot_rows", "cw", "order_preorder"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    if n == 40:
+        np.random.seed(5)
+        assert _replay_native(np.ascontiguousarray(locs), r, M, 4) is None
