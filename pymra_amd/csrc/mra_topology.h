@@ -76,11 +76,14 @@ struct Result {
 // returns 0 on success, 1 if the tree does not follow the large-2-D rules (nothing modified)
 inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out) {
     if (M < 1 || N <= 0 || r <= 0) return 1;
-    // ---- partitions of all levels (they do not depend on the knots)
+    // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the
+    //      row order so every pass is a sequential sweep
     std::vector<std::vector<int64_t>> orders(M + 1), starts(M + 1);
     orders[0].resize(N);
     for (int64_t i = 0; i < N; ++i) orders[0][i] = i;
     starts[0] = {0, N};
+    std::vector<double> cur(xy, xy + 2 * N), nxt_xy(2 * N);
+    std::vector<uint8_t> code(N);
     for (int m = 0; m < M; ++m) {
         const std::vector<int64_t>& ord = orders[m];
         const std::vector<int64_t>& st = starts[m];
@@ -93,11 +96,12 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             const int64_t s = st[j], e = st[j + 1], n = e - s;
             if (n <= 100) return 1;
             double sx = 0.0, sy = 0.0;                       // np.mean(axis=0): sequential accumulation, then / n
-            for (int64_t t = s; t < e; ++t) { sx += xy[2 * ord[t]]; sy += xy[2 * ord[t] + 1]; }
+            for (int64_t t = s; t < e; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
             const double mx = sx / (double)n, my = sy / (double)n;
             int64_t cnt[4] = {0, 0, 0, 0};
             for (int64_t t = s; t < e; ++t) {
-                const int c = 2 * (xy[2 * ord[t]] > mx) + (xy[2 * ord[t] + 1] > my);
+                const uint8_t c = (uint8_t)(2 * (cur[2 * t] > mx) + (cur[2 * t + 1] > my));
+                code[t] = c;
                 ++cnt[c];
             }
             if (!cnt[0] || !cnt[1] || !cnt[2] || !cnt[3]) return 1;
@@ -105,11 +109,14 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
             for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
             for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
-                const int c = 2 * (xy[2 * ord[t]] > mx) + (xy[2 * ord[t] + 1] > my);
-                nxt[off[c]++] = ord[t];
+                const int64_t d = off[code[t]]++;
+                nxt[d] = ord[t];
+                nxt_xy[2 * d] = cur[2 * t];
+                nxt_xy[2 * d + 1] = cur[2 * t + 1];
             }
         }
         nst[4 * nn] = N;
+        cur.swap(nxt_xy);
     }
     // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
     uint32_t key[624];
