@@ -176,12 +176,30 @@ struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; };
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
 
+// ------------------------------------------------------------------------------------------------
+//  XCD-aware problem mapping for the batched kernels.  Workgroups are dealt round-robin over the 8
+//  XCDs (blocks b and b+8 share one, each XCD has its own 4 MiB L2), and the G workgroups of one
+//  problem (one leaf / one node) re-read the same A/B panels.  The grid is 1-D, G * 8 * ceil(nprob/8)
+//  blocks; block b -> XCD lane b & 7, slot b >> 3; problem = (slot / G) * 8 + lane, tile = slot % G:
+//  all tiles of a problem run back to back behind ONE L2 instead of being spread over eight.
+//  Placement is a speed matter only; nothing depends on it for correctness.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool xcd_problem_tile(unsigned G, unsigned nprob, unsigned& prob, unsigned& tile) {
+    const unsigned lane = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned grp = slot / G;
+    tile = slot - grp * G;
+    prob = grp * 8u + lane;
+    return prob < nprob;
+}
+
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp) {
-    const GemmProb pb = probs[blockIdx.y];
+__global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
+    unsigned prob_i, wg_i;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i)) return;
+    const GemmProb pb = probs[prob_i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int tn = (pb.N + 31) >> 5, tm = (pb.M + 31) >> 5;
-    const long tile = (long)blockIdx.x * 4 + wave;
+    const long tile = (long)wg_i * 4 + wave;
     if (tile >= (long)tm * tn) return;
     const int mt = (int)(tile / tn), nt = (int)(tile % tn);
     if (pb.lower && nt > mt) return;
@@ -269,13 +287,15 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
 #define GL_LDS_LD 18      /* doubles per staged row: 16 + 2 pad -> conflict-free 32-byte fragment reads */
 
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp) {
+__global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
     __shared__ __attribute__((aligned(16))) double sA[2][64 * GL_LDS_LD];
     __shared__ __attribute__((aligned(16))) double sB[2][64 * GL_LDS_LD];
-    const GemmProb pb = probs[blockIdx.y];
+    unsigned prob_i, wg_i;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i)) return;
+    const GemmProb pb = probs[prob_i];
     const int tn = (pb.N + 63) >> 6, tm = (pb.M + 63) >> 6;
-    if ((int)blockIdx.x >= tm * tn) return;
-    const int mt = blockIdx.x / tn, nt = blockIdx.x % tn;
+    if ((int)wg_i >= tm * tn) return;
+    const int mt = wg_i / tn, nt = wg_i % tn;
     if (pb.lower && nt > mt) return;
     const int M0 = mt << 6, N0 = nt << 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
@@ -1356,8 +1376,12 @@ __global__ void k_extract_mean(const double* __restrict__ W, long ldw, int Ka, d
     if (p < P) mean[p] = -W[p * ldw + Ka];
 }
 
-// d = sum of per-node log-determinants, in node order (deterministic), one workgroup
-__global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dnode, int n, double* __restrict__ out) {
+// d = sum of per-node log-determinants, in node order (deterministic), one workgroup.  With `up` set
+// this is the last launch of a pass and out[0..3] = {d, u, log-det sum carried by the reduce level,
+// error flag} is the one record the host reads back
+__global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dnode, int n, double* __restrict__ out,
+                                                   const double* __restrict__ up = nullptr, const double* __restrict__ below = nullptr,
+                                                   const int* __restrict__ err = nullptr) {
     __shared__ double part[256];
     double s = 0.0;
     const int chunk = (n + 255) / 256;
@@ -1369,5 +1393,10 @@ __global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dn
         double t = 0.0;
         for (int i = 0; i < 256; ++i) t += part[i];
         out[0] = t;
+        if (up) {
+            out[1] = *up;
+            out[2] = below ? *below : 0.0;
+            out[3] = (double)(*err);
+        }
     }
 }

@@ -136,6 +136,7 @@ struct mra_plan {
     int reduce_level = -1;
     // device data
     DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag;
+    double* host_res = nullptr;      // pinned {d, u, below, err} record of the last pass
     DevVec<int> errflag, knot_idx, row_leaf;
     DevVec<long> knots_dev;
     std::vector<long> knot_idx_off;      // per node offset into knot_idx (padded to cw)
@@ -687,10 +688,12 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
     const bool lds = pl->gemm_lds && allow_lds;
     const unsigned gx = lds ? (unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)) : gemm_grid_x(maxM, maxN);
     const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
-    for (size_t off = 0; off < nprob; off += 65535) {
-        const unsigned gy = (unsigned)std::min<size_t>(65535, nprob - off);
-        dim3 grid(gx, gy);
-#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp)
+    // 1-D grid, XCD-aware (xcd_problem_tile): gx workgroups per problem, problems rounded up to 8
+    const size_t chunk = (size_t)std::max<long>(8, ((0x7fffffffL / (long)gx) / 8) * 8);
+    for (size_t off = 0; off < nprob; off += chunk) {
+        const unsigned gy = (unsigned)std::min<size_t>(chunk, nprob - off);
+        dim3 grid(gx * (((gy + 7u) / 8u) * 8u));
+#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp, gx, gy)
         if (lds) {
             if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 3); }
             else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 3); }
@@ -930,31 +933,30 @@ static void finish_run(mra_plan* pl) {
     {
         KTimer kt(pl, KF_MISC, 0);
         const int nsum = pl->reduce_level >= 0 ? (int)pl->level_ptr[pl->reduce_level + 1] : pl->n_nodes;
-        hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->scal.p);
+        const double* up;
+        if (pl->leaf[0]) up = pl->Gt.p + pl->leaf_goff[pl->leaf_slot[0]] + (size_t)(pl->na[0] - MRA_YB) * pl->na[0] + (pl->na[0] - MRA_YB);
+        else {
+            const LevelData& l0 = pl->lev[0];
+            up = l0.F.p + (size_t)(l0.nf - MRA_YB) * l0.nf + (l0.nf - MRA_YB);
+        }
+        const double* below = nullptr;
+        if (pl->reduce_level >= 0) {
+            const LevelData& lr = pl->lev[pl->reduce_level];
+            if (lr.F.n) below = lr.F.p + (lr.F.n - 16);
+        }
+        hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->scal.p, up, below, pl->errflag.p);
         if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov))
             hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
                                pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
     }
     phase_mark(pl, 5);
+    // one 32-byte record back to the host: {d, u, log-det carried by the reduce level, error flag}
+    if (!pl->host_res) HIP_TRY(hipHostMalloc((void**)&pl->host_res, 4 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(pl->host_res, pl->scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));
     HIP_TRY(hipGetLastError());
-    int errv = 0;
-    HIP_TRY(hipMemcpy(&errv, pl->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
-    double dsum = 0, u = 0;
-    HIP_TRY(hipMemcpy(&dsum, pl->scal.p, sizeof(double), hipMemcpyDeviceToHost));
-    const double* up;
-    if (pl->leaf[0]) up = pl->Gt.p + pl->leaf_goff[pl->leaf_slot[0]] + (size_t)(pl->na[0] - MRA_YB) * pl->na[0] + (pl->na[0] - MRA_YB);
-    else {
-        const LevelData& l0 = pl->lev[0];
-        up = l0.F.p + (size_t)(l0.nf - MRA_YB) * l0.nf + (l0.nf - MRA_YB);
-    }
-    HIP_TRY(hipMemcpy(&u, up, sizeof(double), hipMemcpyDeviceToHost));
-    if (pl->reduce_level >= 0) {
-        double below = 0;
-        const LevelData& lr = pl->lev[pl->reduce_level];
-        if (lr.F.n) HIP_TRY(hipMemcpy(&below, lr.F.p + (lr.F.n - 16), sizeof(double), hipMemcpyDeviceToHost));
-        dsum += below;
-    }
+    const int errv = (int)pl->host_res[3];
+    const double dsum = pl->host_res[0] + pl->host_res[2], u = pl->host_res[1];
     pl->res_d = dsum; pl->res_u = u;
     float ms;
     for (int k = 0; k < 4; ++k) {
@@ -1168,6 +1170,7 @@ int mra_plan_destroy(mra_plan* pl) {
     }
     for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
     if (pl->stream) hipStreamDestroy(pl->stream);
+    if (pl->host_res) hipHostFree(pl->host_res);
     delete pl;
     return MRA_OK;
 }

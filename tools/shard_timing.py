@@ -34,4 +34,13 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     print("world %d: rank-0 local P=%d nodes=%d  %.3f ms/step (incl. host export/import)  reduce buf %.1f KB" % (world, local.P, local.n_nodes, dt, (len(pl.reduce_export()) * 8 / 1024) if False else 0))
     for k in acc:
         if k["launches"]: print("      %-58s %5.1f launches %7.3f ms" % (k["name"], k["launches"] / n, k["ms"] / n))
+    # device wall-clock per step without per-kernel events and without the host export/import hop
+    pl.set_option(1, 0)
+    def step2():
+        if red < 0: pl.run(True, True); return
+        pl.run(True, True, split=True); pl.resume()
+    for _ in range(3): step2()
+    n2 = 50; t0 = time.perf_counter()
+    for _ in range(n2): step2()
+    print("      plain: %.3f ms/step wall (no kernel events, no host hop); device phases %s" % ((time.perf_counter() - t0) / n2 * 1e3, {k: round(v, 3) for k, v in pl.timers().items()}))
     pl.close()
