@@ -441,40 +441,84 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
 // ------------------------------------------------------------------------------------------------
 //  16x16 diagonal block: Cholesky + inverse of the factor, one row per lane (lanes 0..15)
 // ------------------------------------------------------------------------------------------------
-// a[k] = T[lane][k] (k <= lane valid).  On return a[k] = L[lane][k] (0 above the diagonal),
-// m[i] = (L^{-1})[i][lane] (column `lane` of the inverse).  Returns sum(log diag L) and sets bad
-// when a pivot is not positive.  Broadcasts go through v_readlane (scalar registers), not LDS.
-__device__ __forceinline__ double bcast_lane(double x, int src) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
+// a[k] = T[lane][k] (k <= lane valid, 0 above the diagonal).  On return a[k] = L[lane][k] (0 above the
+// diagonal), mr[k] = (L^{-1})[lane][k] (row `lane` of the inverse, 0 above the diagonal).  Returns sum(log diag L) and sets
+// bad when a pivot is not positive.  All 64 lanes call it with lane = (lane id & 15) (the four 16-lane
+// groups do the same work); sc = 272 doubles of LDS scratch private to the wave.
+//
+// This serial 16x16 step is the latency floor of every small factorisation on the path (knot pass,
+// fronts, the leaves' C blocks), so it is written for a short dependent chain rather than for
+// throughput: right-looking with one row per lane; per column the un-normalised entries c_i = A[i][j]
+// go through LDS once (one ds_write_b64, broadcast ds_reads) and every lane applies
+// A[i][k] -= (c_i / d_j) c_k with its own Newton reciprocal of the pivot d_j = c_j.  Square roots
+// (v_rsq_f64 + Goldschmidt, no division) are off the critical path: L[i][j] = c_i * rsqrt(d_j).
+// The inverse comes from applying the same row operations to the identity (row j of the unit-lower
+// inverse is final at step j and rides the same LDS exchange), scaled by rsqrt(d_i) at the end.
+__device__ __forceinline__ void lds_wave_sync() {
+    // LDS operations of one wave complete in program order; this only stops the compiler from moving
+    // or forwarding memory accesses across the exchange
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ double chol16_inv(double a[16], double m[16], int lane, bool& bad) {
-    double rinv[16];
+__device__ __forceinline__ double rcp_pos(double d) {            // 1/d, d > 0 normal: v_rcp_f64 + 2 Newton steps
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double rsqrt_pos(double d) {          // 1/sqrt(d), d > 0 normal
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    h = __builtin_fma(h, e, h);
+    return h + h;
+}
+__device__ __forceinline__ double chol16_inv(double a[16], double mr[16], int lane, bool& bad, double* __restrict__ sc) {
+    // opaque copy of the lane number: keeps the per-lane masks / unit vectors below from being hoisted
+    // out of the caller's tile loop (dozens of live registers across the whole factorisation)
+    asm volatile("" : "+v"(lane));
+    double* col = sc + 256;
+    double dsel = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mr[k] = (k == lane) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        double dj = bcast_lane(a[j], j);
-        if (!(dj > 0.0)) { bad = true; dj = 1.0; }
-        const double sq = sqrt(dj);
-        const double ri = 1.0 / sq;
-        rinv[j] = ri;
-        const double lij = (lane == j) ? sq : ((lane > j) ? a[j] * ri : 0.0);
-        a[j] = lij;
+        col[lane] = a[j];
+        if (lane == j) {                 // row j of the unit-lower inverse is final: share it
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) a[k] -= lij * bcast_lane(lij, k);
+            for (int k = 0; k <= j; k += 2) *(double2*)(sc + j * 16 + k) = double2{mr[k], mr[k + 1]};
+        }
+        lds_wave_sync();
+        double c[16], mj[16];
+#pragma unroll
+        for (int k = j; k < 16; ++k) c[k] = col[k];
+#pragma unroll
+        for (int k = 0; k <= j; ++k) mj[k] = sc[j * 16 + k];
+        lds_wave_sync();
+        double d = c[j];
+        if (!(d > 0.0)) { bad = true; d = 1.0; }
+        const double t = (lane > j) ? a[j] * rcp_pos(d) : 0.0;
+        // the empty asm pins each update to its step: left alone the compiler sinks all of them to
+        // their first use (a left-looking schedule that keeps every earlier column live in registers)
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) { a[k] = __builtin_fma(-t, c[k], a[k]); asm volatile("" : "+v"(a[k])); }
+#pragma unroll
+        for (int k = 0; k <= j; ++k) { mr[k] = __builtin_fma(-t, mj[k], mr[k]); asm volatile("" : "+v"(mr[k])); }
+        a[j] *= rsqrt_pos(d);
+        dsel = (lane == j) ? d : dsel;
     }
-    // forward substitution L m = e_lane, every lane its own right-hand side
+    const double rsl = rsqrt_pos(dsel);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double acc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) acc -= bcast_lane(a[k], i) * m[k];
-        m[i] = acc * rinv[i];
-    }
-    double dg = a[0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) dg = (lane == i) ? a[i] : dg;
-    double lg = log(dg);
+    for (int k = 0; k < 16; ++k) mr[k] *= rsl;
+    double lg = 0.5 * log(dsel);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
     return lg;
@@ -495,7 +539,7 @@ struct PanelProb {
 __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict__ probs,
                                                      double* __restrict__ dnode, int* __restrict__ err) {
     const PanelProb pb = probs[blockIdx.x];
-    __shared__ double sd[16][17];
+    __shared__ __attribute__((aligned(16))) double sd[16][17];
     __shared__ double sinv[16][17];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     double logacc = 0.0;
@@ -530,7 +574,7 @@ __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict_
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= rl) ? sd[rl][k] : 0.0;
             bool bad = false;
-            double ls = chol16_inv(a, m, rl, bad);
+            double ls = chol16_inv(a, m, rl, bad, &sd[0][0]);
             logacc += ls;
             if (lane < 16) {
                 double* dp = pb.P + (long)(jb * 16 + lane) * pb.ld + jb * 16;
@@ -538,7 +582,7 @@ __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict_
                 for (int k = 0; k < 16; ++k) dp[k] = a[k];
                 double* ip = pb.invd + (long)jb * 256;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { sinv[i][lane] = m[i]; ip[i * 16 + lane] = m[i]; }
+                for (int k = 0; k < 16; ++k) { sinv[lane][k] = m[k]; ip[lane * 16 + k] = m[k]; }
                 if (bad && lane == 0) atomicMax(err, pb.node + 1);
             }
         }
@@ -598,14 +642,14 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
             double a[16], m[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? sd[r * 16 + k] : 0.0;
-            logacc += chol16_inv(a, m, r, bad);
+            logacc += chol16_inv(a, m, r, bad, sd);
             if (lane < 16) {
                 double* dp = P + (long)(jb * 16 + lane) * ld + jb * 16;
                 double* ip2 = invd + (long)jb * 256;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) dp[k] = a[k];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { si[i * 16 + lane] = m[i]; ip2[i * 16 + lane] = m[i]; }
+                for (int k = 0; k < 16; ++k) { si[lane * 16 + k] = m[k]; ip2[lane * 16 + k] = m[k]; }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -635,7 +679,7 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
 template <int NTMAX>
 __global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
                                                     double* __restrict__ dnode, int* __restrict__ err) {
-    __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16];
+    __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16 + 32];     // 272 used: tile + exchange column
     __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ip = blockIdx.x * 4 + wave;
@@ -1069,7 +1113,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
         // ---- the node's kInv, factor and inverted diagonal blocks, still in this launch
         constexpr int CW = CWT * 16;
         double* s_sd = lds;            // the staged operands are dead by now: reuse the dynamic LDS as scratch
-        double* s_si = lds + 256;
+        double* s_si = lds + 288;      // s_sd: 272 doubles (tile + exchange column of chol16_inv)
         const int mo = ar.mlast + 1;
         const int slotk = chain[mo];
         const int Kw = mo * CW;

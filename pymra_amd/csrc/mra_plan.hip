@@ -744,10 +744,10 @@ static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
     }
     if (pl->cascade_stage_all)
         hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 512),
-                           std::max<size_t>(pl->cascade_lds_all, 4096), pl->stream, ar, pl->kp);
+                           std::max<size_t>(pl->cascade_lds_all, 8192), pl->stream, ar, pl->kp);
     else
         hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw),
-                           std::max<size_t>(pl->cascade_lds, 4096), pl->stream, ar, pl->kp);
+                           std::max<size_t>(pl->cascade_lds, 8192), pl->stream, ar, pl->kp);
 }
 template <int CWT, int NLMAX>
 static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {

@@ -1,0 +1,81 @@
+// Micro-benchmark of the small-factorisation latency chain: one chol16_inv call, a dependent MFMA chain, and
+// the leaf-C Cholesky kernels (k_chol_wave, k_panel_chol) on 1 / 512 / 4096 matrices of 7x7 tiles.
+// Measured on MI355X: chol16_inv 3.3 us per call; dependent v_mfma_f64_16x16x4 73 ns each (29 ns when
+// independent); one 112x112 factorisation ~60 us whichever kernel (an LDS-resident one-workgroup variant was
+// no faster: 59 us) - the floor is the serial chain 7 x (diagonal block + dependent MFMA updates).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/chol_latency.hip -o tools/chol_latency && tools/chol_latency
+#include "../pymra_amd/csrc/mra_kernels.h"
+#include <cstdio>
+#include <vector>
+
+__global__ __launch_bounds__(64) void k_c16(double* out, int iters) {
+    __shared__ __attribute__((aligned(16))) double sc[288];
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    double a0[16];
+    for (int k = 0; k < 16; ++k) a0[k] = (k < r) ? 1.0 / (1 + r - k) : (k == r ? 20.0 : 0.0);
+    double acc = 0;
+    bool bad = false;
+    for (int it = 0; it < iters; ++it) {
+        double a[16], m[16];
+        for (int k = 0; k < 16; ++k) a[k] = a0[k];
+        const double lg = chol16_inv(a, m, r, bad, sc);
+        acc += lg + m[3] + a[2];
+        a0[r > 15 ? 0 : 15] += 1e-30 * acc;       // keep the calls dependent
+    }
+    out[threadIdx.x] = acc + (bad ? 1 : 0);
+}
+
+__global__ __launch_bounds__(64) void k_mfma_chain(double* out, int iters) {
+    d4 acc = {0, 0, 0, 0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0;
+    for (int it = 0; it < iters; ++it) acc = mfma16(a, b, acc);
+    out[threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+int main() {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double* dout; hipMalloc(&dout, 1 << 20);
+    float ms;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0); hipLaunchKernelGGL(k_c16, dim3(1), dim3(64), 0, 0, dout, 2000); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("chol16_inv: %.3f us per call (one wave, dependent calls)\n", ms * 1e3 / 2000);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0); hipLaunchKernelGGL(k_mfma_chain, dim3(1), dim3(64), 0, 0, dout, 100000); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    printf("dependent mfma_f64_16x16x4: %.1f ns each\n", ms * 1e6 / 100000);
+
+    const int nt = 7, n = nt * 16, nmax = 4096;
+    std::vector<double> h((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) h[(size_t)i * n + j] = (i == j ? 3.0 : 0.0) + 1.0 / (1.0 + abs(i - j));
+    double *dP, *dP0, *dinv, *dnode; int* derr; PanelProb* dprob;
+    hipMalloc(&dP0, (size_t)n * n * 8); hipMemcpy(dP0, h.data(), (size_t)n * n * 8, hipMemcpyHostToDevice);
+    hipMalloc(&dP, (size_t)nmax * n * n * 8); hipMalloc(&dinv, (size_t)nmax * nt * 256 * 8); hipMalloc(&dnode, nmax * 8); hipMalloc(&derr, 4);
+    hipMemset(derr, 0, 4);
+    std::vector<PanelProb> pr(nmax);
+    for (int t = 0; t < nmax; ++t) pr[t] = PanelProb{dP + (size_t)t * n * n, dinv + (size_t)t * nt * 256, n, nt, nt, t};
+    hipMalloc(&dprob, nmax * sizeof(PanelProb)); hipMemcpy(dprob, pr.data(), nmax * sizeof(PanelProb), hipMemcpyHostToDevice);
+    const int counts[3] = {1, 512, 4096};
+    for (int which = 1; which < 3; ++which)
+        for (int ci = 0; ci < 3; ++ci) {
+            const int cnt = counts[ci];
+            float best = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                for (int t = 0; t < cnt; ++t) hipMemcpyAsync(dP + (size_t)t * n * n, dP0, (size_t)n * n * 8, hipMemcpyDeviceToDevice, 0);
+                hipDeviceSynchronize();
+                hipEventRecord(e0);
+                if (which == 1) hipLaunchKernelGGL((k_chol_wave<12>), dim3((cnt + 3) / 4), dim3(256), 0, 0, dprob, cnt, dnode, derr);
+                else hipLaunchKernelGGL(k_panel_chol, dim3(cnt), dim3(256), 0, 0, dprob, dnode, derr);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            double d0; hipMemcpy(&d0, dnode, 8, hipMemcpyDeviceToHost);
+            printf("%-13s %5d matrices of %dx%d: %8.1f us   (logdet %.12f)\n", which == 1 ? "k_chol_wave" : "k_panel_chol", cnt, n, n, best * 1e3, d0);
+        }
+    int e; hipMemcpy(&e, derr, 4, hipMemcpyDeviceToHost);
+    printf("err flag %d\n", e);
+    return 0;
+}
