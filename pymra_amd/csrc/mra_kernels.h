@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define MRA_YB 16
 
@@ -750,6 +751,29 @@ __global__ __launch_bounds__(256) void k_trsm_rows(const TrsmNode* __restrict__ 
 //  in vec layout again (column pi(q + 4 s) = 4 q + s), so solved tiles chain as B operands and are
 //  stored with 32-byte accesses.
 // ------------------------------------------------------------------------------------------------
+//  Staging of 16x16 operand tiles (2 KB each = 128 16-byte chunks, LDS image linear in the chunk
+//  number) with G loads of every thread in flight at once: a plain load -> ds_write loop serialises
+//  one L2 round trip (~1 us) per chunk.  (Register arrays use the native vector type d2: arrays of
+//  HIP's double2 class are not promoted to registers and end up in scratch memory.)
+// ------------------------------------------------------------------------------------------------
+template <int G, class SrcFn>
+__device__ __forceinline__ void stage_chunks(double* __restrict__ ldsb, int total, SrcFn src) {
+    for (int e0 = threadIdx.x; e0 < total; e0 += G * (int)blockDim.x) {
+        d2 v[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int e = e0 + g * (int)blockDim.x;
+            v[g] = *(const d2*)src(e < total ? e : total - 1);       // clamped: always a valid address
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int e = e0 + g * (int)blockDim.x;
+            if (e < total) *(d2*)(ldsb + 2 * e) = v[g];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct Trsm2Prob {
     const double* L;      // nt*16 square lower-triangular factor, row-major
     const double* invd;   // nt inverted 16x16 diagonal blocks (row-major, 256 doubles each)
@@ -779,19 +803,16 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
     const int nt = pb.nt;
     const int ntri = nt * (nt - 1) / 2;
     // ---- stage L (strictly-lower tiles, index jb(jb-1)/2+kb) and invd (after them) in LDS
-    for (int e = threadIdx.x; e < (ntri + nt) * 128; e += blockDim.x) {     // 128 16-byte chunks per tile
+    stage_chunks<8>(lds, (ntri + nt) * 128, [&](int e) -> const double* {
         const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
-        const double* src;
         if (tile < ntri) {
             int jb = 1;
             while ((jb + 1) * jb / 2 <= tile) ++jb;
             const int kb = tile - jb * (jb - 1) / 2;
-            src = pb.L + (long)(jb * 16 + row) * pb.ldL + kb * 16 + c2;
-        } else {
-            src = pb.invd + (long)(tile - ntri) * 256 + row * 16 + c2;
+            return pb.L + (long)(jb * 16 + row) * pb.ldL + kb * 16 + c2;
         }
-        *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
-    }
+        return pb.invd + (long)(tile - ntri) * 256 + row * 16 + c2;
+    });
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int nwave = blockDim.x >> 6;
@@ -911,23 +932,21 @@ __device__ __forceinline__ void cascade_stage_level(const CascadeArgs& ar, int m
     const double* Lm = lv.L + (long)slot * CW * CW;
     const double* inv = lv.invd + (long)slot * CWT * 256;
     const int nwk = CWT * m * CWT;
-    for (int e = threadIdx.x; e < (nwk + NTRI + CWT) * 128; e += blockDim.x) {
+    stage_chunks<8>(ldsb, (nwk + NTRI + CWT) * 128, [&](int e) -> const double* {
         const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
-        const double* src;
         if (tile < nwk) {
             const int jb = tile / (m * CWT), kk = tile % (m * CWT);
-            src = Wk + (long)(jb * 16 + row) * (m * CW) + kk * 16 + c2;
-        } else if (tile < nwk + NTRI) {
+            return Wk + (long)(jb * 16 + row) * (m * CW) + kk * 16 + c2;
+        }
+        if (tile < nwk + NTRI) {
             const int tt = tile - nwk;
             int jb = 1;
             while ((jb + 1) * jb / 2 <= tt) ++jb;
             const int kb = tt - jb * (jb - 1) / 2;
-            src = Lm + (long)(jb * 16 + row) * CW + kb * 16 + c2;
-        } else {
-            src = inv + (long)(tile - nwk - NTRI) * 256 + row * 16 + c2;
+            return Lm + (long)(jb * 16 + row) * CW + kb * 16 + c2;
         }
-        *(double2*)(ldsb + tile * 256 + row * 16 + c2) = *(const double2*)src;
-    }
+        return inv + (long)(tile - nwk - NTRI) * 256 + row * 16 + c2;
+    });
 }
 
 template <int CWT, int NLMAX, int DIM, int MODE>
@@ -1179,11 +1198,46 @@ struct PredArgs {
     int nl;                   // number of non-leaf levels
 };
 
-template <int CWT, int NLMAX>
-__global__ __launch_bounds__(512) void k_predict_cascade(PredArgs ar) {
+#define MRA_PRED_STAGE_ISSUE(ms) do { \
+                const int ms_ = (ms); \
+                const PredLevel ls = ar.lev[ms_]; \
+                const int slot_s = chain[ms_]; \
+                const double* Fs = ls.F + (long)slot_s * ls.nf * ls.nf; \
+                const double* invs = ls.invF + (long)slot_s * CWT * 256; \
+                const int total = (NTRI + CWT + (ms_ * CWT + 1) * CWT) * 128; \
+_Pragma("unroll") \
+                for (int i = 0; i < PMAX; ++i) { \
+                    if (i * NTH < total) { \
+                        int e = (int)threadIdx.x + i * NTH; \
+                        e = e < total ? e : total - 1; \
+                        const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1; \
+                        const double* src; \
+                        if (tile < NTRI) { \
+                            int jb = 1; \
+_Pragma("unroll") \
+                            for (int c = 1; c < CWT - 1; ++c) jb += (tile >= c * (c + 1) / 2) ? 1 : 0; \
+                            const int kb = tile - jb * (jb - 1) / 2; \
+                            src = Fs + (long)(jb * 16 + row) * ls.nf + kb * 16 + c2; \
+                        } else if (tile < NTRI + CWT) { \
+                            src = invs + (long)(tile - NTRI) * 256 + row * 16 + c2; \
+                        } else { \
+                            const int zt = tile - NTRI - CWT, a = zt / CWT, jb = zt % CWT; \
+                            src = Fs + (long)(CW + a * 16 + row) * ls.nf + jb * 16 + c2; \
+                        } \
+                        pre[i] = *(const d2*)src; \
+                    } \
+                } \
+} while (0)
+template <int CWT, int NLMAX, int WPW>
+__global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int CW = CWT * 16;
     constexpr int NTRI = CWT * (CWT - 1) / 2;
+    constexpr int NTH = 64 * WPW;
+    // staging registers: the 16-byte chunks of one level's operand tiles this thread moves (level m has
+    // NTRI + CWT + (m CWT + 1) CWT tiles of 128 chunks)
+    constexpr int PMAX = ((NTRI + CWT + ((NLMAX - 1) * CWT + 1) * CWT) * 128 + NTH - 1) / NTH;
+    d2 pre[PMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const long t0 = ar.wg_tile0[blockIdx.x];
     const int nt_wg = ar.wg_ntiles[blockIdx.x];
@@ -1213,25 +1267,24 @@ __global__ __launch_bounds__(512) void k_predict_cascade(PredArgs ar) {
             const double* F = lv.F + (long)slot * lv.nf * lv.nf;
             const double* inv = lv.invF + (long)slot * CWT * 256;
             const int nzt = (m * CWT + 1) * CWT;            // Zt tiles: ancestors' tiles + the y tile, CWT k-tiles each
-            // ---- stage: Lt strictly-lower tiles, inverted diagonal blocks, Zt tiles [a][jb]
-            __syncthreads();
-            for (int e = threadIdx.x; e < (NTRI + CWT + nzt) * 128; e += blockDim.x) {
-                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
-                const double* src;
-                if (tile < NTRI) {
-                    int jb = 1;
-                    while ((jb + 1) * jb / 2 <= tile) ++jb;
-                    const int kb = tile - jb * (jb - 1) / 2;
-                    src = F + (long)(jb * 16 + row) * lv.nf + kb * 16 + c2;
-                } else if (tile < NTRI + CWT) {
-                    src = inv + (long)(tile - NTRI) * 256 + row * 16 + c2;
-                } else {
-                    const int zt = tile - NTRI - CWT, a = zt / CWT, jb = zt % CWT;
-                    src = F + (long)(CW + a * 16 + row) * lv.nf + jb * 16 + c2;
+            // ---- stage: Lt strictly-lower tiles, inverted diagonal blocks, Zt tiles [a][jb].  All of a
+            // thread's loads are issued together, and the loads of level m-1 are issued BEFORE the
+            // products of level m, so their L2 round trip (a load -> ds_write loop pays ~1 us per
+            // chunk, which was half of this kernel's run time) hides behind the MFMA work.
+            if (m == ar.nl - 1) MRA_PRED_STAGE_ISSUE(m);               // the first (deepest) level of this tree
+            __syncthreads();                                  // the previous level's products are done with the LDS image
+            {
+                const int total = (NTRI + CWT + nzt) * 128;
+#pragma unroll
+                for (int i = 0; i < PMAX; ++i) {
+                    if (i * NTH < total) {
+                        const int e = (int)threadIdx.x + i * NTH;
+                        if (e < total) *(d2*)(lds + 2 * e) = pre[i];
+                    }
                 }
-                *(double2*)(lds + tile * 256 + row * 16 + c2) = *(const double2*)src;
             }
             __syncthreads();
+            if (m > 0) MRA_PRED_STAGE_ISSUE(m - 1);
             if (active) {
                 d4 x[CWT];
 #pragma unroll

@@ -186,7 +186,7 @@ struct mra_plan {
     long n_ftiles = 0, n_fwg = 0;
     size_t cascade_lds = 0, cascade_lds_all = 0;
     bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
-    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels
+    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels (4 or 8; 4 measured faster)
     DevVec<long> ft_wg0_leaf;
     DevVec<int> ft_wgn_leaf;
     long n_fwg_leaf = 0;
@@ -817,11 +817,17 @@ static void run_prior_fused(mra_plan* pl) {
     }
 }
 
+template <int CWT, int NLMAX, int WPW>
+static void launch_predict_cascade_w(mra_plan* pl, const PredArgs& ar, size_t lds) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+}
 template <int CWT, int NLMAX>
 static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX>), dim3((unsigned)ar.n_wg), dim3(64 * pl->cascade_wpw), lds, pl->stream, ar);
+    if (pl->cascade_wpw == 8) launch_predict_cascade_w<CWT, NLMAX, 8>(pl, ar, lds);
+    else if (pl->cascade_wpw == 4) launch_predict_cascade_w<CWT, NLMAX, 4>(pl, ar, lds);
+    else throw MraError(MRA_ERR_STATE, "cascade_wpw must be 4 or 8");
 }
 
 static void run_predict_fused(mra_plan* pl) {
