@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, con
 
 template <int CWT, int NLMAX>
 __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int* chain, long t, long myrow, bool phantom_row,
-                                                d4 (&w)[NLMAX][CWT], int r, int q) {
+                                                d4 (&w)[NLMAX][CWT], int r, int q, double ssq) {
     constexpr int CW = CWT * 16;
     const d4 zero = {0, 0, 0, 0};
     if (ar.knot_mode) {
@@ -1021,19 +1021,8 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
         }
         return;
     }
-    double* o = ar.W + myrow * ar.ldw;
-    double ssq = 0.0;
-#pragma unroll
-    for (int m = 0; m < NLMAX; ++m) {
-        if (m <= ar.mlast) {
-#pragma unroll
-            for (int jb = 0; jb < CWT; ++jb) {
-                const d4 v = w[m][jb];
-                *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
-                ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-            }
-        }
-    }
+    // row mode: the W tiles and the Ut columns of each level were written by cascade_output_level right
+    // after the level was computed; what is left is the residual prior variance and the y entry of Ut
     if (ar.var_out) {
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
@@ -1041,24 +1030,39 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
     }
     if (ar.obs_pos) {
         const int op = ar.obs_pos[myrow];
-        if (op >= 0) {
+        if (op >= 0 && q == 0) {
             const int lf = ar.tile_leaf[t];
-            double* ut = ar.leaf_ut[lf];
-            const long nop = ar.leaf_nop[lf];
-#pragma unroll
-            for (int m = 0; m < NLMAX; ++m) {
-                if (m <= ar.mlast) {
-#pragma unroll
-                    for (int jb = 0; jb < CWT; ++jb) {
-                        const d4 v = w[m][jb];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
-                    }
-                }
-            }
-            if (q == 0) ut[(long)ar.ut_yrow * nop + op] = ar.y[myrow];
+            ar.leaf_ut[lf][(long)ar.ut_yrow * ar.leaf_nop[lf] + op] = ar.y[myrow];
         }
     }
+}
+
+// Row mode, level m just computed: its W tiles go out now (stores spread over the whole cascade drain while
+// the next levels are on the MFMA pipe; issued in one burst at the end they cost ~0.4 ms at C3), the
+// observed rows also into the leaf's Ut (transposed).  Returns the row's sum of squares of the level.
+template <int CWT, int NLMAX>
+__device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, int m, long t, long myrow, int op,
+                                                       const d4 (&w)[NLMAX][CWT], int q) {
+    double* o = ar.W + myrow * ar.ldw;
+    double ssq = 0.0;
+#pragma unroll
+    for (int jb = 0; jb < CWT; ++jb) {
+        const d4 v = w[m][jb];
+        *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+        ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (op >= 0) {
+        const int lf = ar.tile_leaf[t];
+        double* ut = ar.leaf_ut[lf];
+        const long nop = ar.leaf_nop[lf];
+#pragma unroll
+        for (int jb = 0; jb < CWT; ++jb) {
+            const d4 v = w[m][jb];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
+        }
+    }
+    return ssq;
 }
 
 // One workgroup = the row tiles of one leaf (FULL) or the knot tiles of one node (KNOT): they share
@@ -1095,11 +1099,15 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
 #pragma unroll
             for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
             d4 w[NLMAX][CWT];
+            double ssq = 0.0;
+            const int op = (!ar.knot_mode && ar.obs_pos) ? ar.obs_pos[myrow] : -1;
 #pragma unroll
             for (int m = 0; m < NLMAX; ++m)
-                if (m <= ar.mlast)
+                if (m <= ar.mlast) {
                     cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds + cascade_level_off<CWT>(m) * 256, w, xr, prow, q);
-            cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q);
+                    if (!ar.knot_mode) ssq += cascade_output_level<CWT, NLMAX>(ar, m, t, myrow, op, w, q);
+                }
+            cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
         }
     } else {
         const bool active = wave < nt_wg;
@@ -1117,16 +1125,21 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
 #pragma unroll
         for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
         d4 w[NLMAX][CWT];
+        double ssq = 0.0;
+        const int op = (!ar.knot_mode && ar.obs_pos) ? ar.obs_pos[myrow] : -1;
 #pragma unroll
         for (int m = 0; m < NLMAX; ++m) {
             if (m <= ar.mlast) {
                 __syncthreads();
                 cascade_stage_level<CWT>(ar, m, chain[m], lds);
                 __syncthreads();
-                if (active) cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds, w, xr, prow, q);
+                if (active) {
+                    cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds, w, xr, prow, q);
+                    if (!ar.knot_mode) ssq += cascade_output_level<CWT, NLMAX>(ar, m, t, myrow, op, w, q);
+                }
             }
         }
-        if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q);
+        if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
     }
     if (ar.knot_mode && ar.Lp_out) {
         // ---- the node's kInv, factor and inverted diagonal blocks, still in this launch
