@@ -26,6 +26,22 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// Pointers that reach a kernel inside a descriptor read from memory (GemmProb, PanelProb, ...) are
+// generic to the compiler, and every access through them becomes a FLAT instruction: those count on
+// lgkmcnt as well as vmcnt, so each s_waitcnt lgkmcnt(0) in front of an LDS-fed MFMA group also waits
+// for the global prefetches in flight, and the loop falls back to vmcnt(0).  Telling the compiler that
+// Accesses through such pointers therefore go through these helpers, which cast to the global address
+// space at the access and give global_load / global_store.
+#define MRA_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ double gld(const double* p) { return *(const double MRA_AS1*)p; }
+__device__ __forceinline__ int gldi(const int* p) { return *(const int MRA_AS1*)p; }
+__device__ __forceinline__ d2 gld2(const double* p) { return *(const d2 MRA_AS1*)p; }
+__device__ __forceinline__ d4 gld4(const double* p) { return *(const d4 MRA_AS1*)p; }
+__device__ __forceinline__ void gst(double* p, double v) { *(double MRA_AS1*)p = v; }
+__device__ __forceinline__ void gst2(double* p, d2 v) { *(d2 MRA_AS1*)p = v; }
+__device__ __forceinline__ void gst4(double* p, d4 v) { *(d4 MRA_AS1*)p = v; }
+
+
 #define MRA_YB 16
 
 // row permutation of the "vec" tile layout (see k_trsm_rows2)
@@ -286,6 +302,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
 //  direct-load kernel above; same GemmProb, same epilogues.
 // ------------------------------------------------------------------------------------------------
 #define GL_LDS_LD 18      /* doubles per staged row: 16 + 2 pad -> conflict-free 32-byte fragment reads */
+#define GL_PF 2           /* K-steps the global loads run ahead (register sets); even */
 
 template <int EPI, int DIM, int MODE>
 __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
@@ -305,28 +322,47 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
     const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
     bool a_ok = (M0 + srow) < pb.M;
     long arow = M0 + srow;
-    if (a_ok && pb.idxA) { const int ia = pb.idxA[arow]; a_ok = ia >= 0; arow = a_ok ? ia : 0; }
+    if (a_ok && pb.idxA) { const int ia = gldi(pb.idxA + arow); a_ok = ia >= 0; arow = a_ok ? ia : 0; }
     const double* ap = pb.A + (a_ok ? arow : 0) * pb.lda + sch;
     long brow = N0 + srow;
     bool b_ok = brow < pb.N;
-    if (b_ok && pb.idxB) { const int ib = pb.idxB[brow]; b_ok = ib >= 0; brow = b_ok ? ib : 0; }
+    if (b_ok && pb.idxB) { const int ib = gldi(pb.idxB + brow); b_ok = ib >= 0; brow = b_ok ? ib : 0; }
     const double* bp = pb.B + (b_ok ? brow : 0) * pb.ldb + sch;
     const d4 zero = {0, 0, 0, 0};
     d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
     const int nk = pb.K >> 4;
-    // register prefetch two K-steps ahead (two register sets, statically indexed by unrolling by 2),
-    // LDS double-buffered: the global load of step k+2 is in flight during the whole of step k
-    d4 ra0 = zero, rb0 = zero, ra1 = zero, rb1 = zero;
-    if (nk > 0) {
-        ra0 = a_ok ? *(const d4*)ap : zero;
-        rb0 = b_ok ? *(const d4*)bp : zero;
-        *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra0;
-        *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb0;
+    // Global loads run GL_PF K-steps ahead of the MFMAs through GL_PF register sets (statically indexed:
+    // the loop is unrolled by GL_PF); the LDS stage is double-buffered.  What-if runs showed this
+    // kernel bound by the latency of its operand stream, not by the MFMA pipe (all MFMAs removed:
+    // 1.52 -> 1.27 ms for the leaf update), with loads only two steps ahead.
+    // Every load is unconditional (rows that do not exist read row 0 and are zeroed on their way into
+    // LDS; steps past the end re-read the last step): a load inside a branch makes the compiler fall
+    // back to s_waitcnt vmcnt(0) in the loop, which waits for the prefetches just issued as well.
+    d4 ra[GL_PF], rb[GL_PF];
+    const int klast = (nk > 0 ? nk - 1 : 0) * 16;
+#pragma unroll
+    for (int i = 0; i < GL_PF; ++i) {
+        const int ko = i < nk ? i * 16 : klast;
+        ra[i] = gld4(ap + ko);
+        rb[i] = gld4(bp + ko);
     }
-    if (nk > 1) {
-        ra1 = a_ok ? *(const d4*)(ap + 16) : zero;
-        rb1 = b_ok ? *(const d4*)(bp + 16) : zero;
+    // SUB: the C tile this wave is going to update is fetched now, not after the K loop (sixteen
+    // dependent 8-byte loads at the tail of every workgroup cost ~0.27 ms of the leaf update)
+    const int pm0 = M0 + wm * 32, pn0 = N0 + wn * 32;
+    d4 cin[4] = {zero, zero, zero, zero};
+    if (EPI == EPI_SUB && pm0 < pb.M && pn0 < pb.N) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int mb = pm0 + (t4 >> 1) * 16, nb = pn0 + (t4 & 1) * 16;
+            const int col = nb + r;
+            if (mb < pb.M && nb < pb.N && !(pb.zc > 0 && col >= pb.zc)) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
+            }
+        }
     }
+    *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = a_ok ? ra[0] : zero;
+    *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = b_ok ? rb[0] : zero;
     __syncthreads();
     const int arow0 = (wm * 32 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
     const int brow0 = (wn * 32 + r) * GL_LDS_LD + 4 * q, brow1 = brow0 + 16 * GL_LDS_LD;
@@ -367,44 +403,36 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
             }
         }
     };
-    for (int ks = 0; ks < nk; ks += 2) {
-        // ---- even step: LDS buffer 0 holds step ks; registers set 1 holds step ks+1; fetch ks+2 into set 0
-        if (ks + 2 < nk) {
-            ra0 = a_ok ? *(const d4*)(ap + (ks + 2) * 16) : zero;
-            rb0 = b_ok ? *(const d4*)(bp + (ks + 2) * 16) : zero;
+    for (int ks0 = 0; ks0 < nk; ks0 += GL_PF) {
+#pragma unroll
+        for (int i = 0; i < GL_PF; ++i) {
+            const int ks = ks0 + i;                        // LDS buffer i & 1 holds step ks (GL_PF is even)
+            if (ks < nk) {
+                {                                          // register set i is free again: refill it GL_PF steps ahead
+                    const int ko = (ks + GL_PF < nk) ? (ks + GL_PF) * 16 : klast;
+                    ra[i] = gld4(ap + ko);
+                    rb[i] = gld4(bp + ko);
+                }
+                compute(i & 1);
+                *(d4*)(&sA[(i + 1) & 1][srow * GL_LDS_LD + sch]) = a_ok ? ra[(i + 1) % GL_PF] : zero;
+                *(d4*)(&sB[(i + 1) & 1][srow * GL_LDS_LD + sch]) = b_ok ? rb[(i + 1) % GL_PF] : zero;
+                __syncthreads();
+            }
         }
-        compute(0);
-        if (ks + 1 < nk) {
-            *(d4*)(&sA[1][srow * GL_LDS_LD + sch]) = ra1;
-            *(d4*)(&sB[1][srow * GL_LDS_LD + sch]) = rb1;
-        }
-        __syncthreads();
-        if (ks + 1 >= nk) break;
-        // ---- odd step: LDS buffer 1 holds step ks+1; registers set 0 holds step ks+2; fetch ks+3 into set 1
-        if (ks + 3 < nk) {
-            ra1 = a_ok ? *(const d4*)(ap + (ks + 3) * 16) : zero;
-            rb1 = b_ok ? *(const d4*)(bp + (ks + 3) * 16) : zero;
-        }
-        compute(1);
-        if (ks + 2 < nk) {
-            *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = ra0;
-            *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = rb0;
-        }
-        __syncthreads();
     }
     // ---- epilogue (as k_gemm_nt): accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
     const int m0 = M0 + wm * 32, n0 = N0 + wn * 32;
     if (m0 >= pb.M || n0 >= pb.N) return;
     const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
     int bc0 = n0 + r, bc1 = n0 + 16 + r;
-    if (pb.idxB) { bc0 = pb.idxB[n0 + r]; bc1 = nv1 ? pb.idxB[n0 + 16 + r] : -1; }
-    auto emit = [&](d4 acc, int mb, int nb, int bcol) {
+    if (pb.idxB) { bc0 = gldi(pb.idxB + n0 + r); bc1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1; }
+    auto emit = [&](d4 acc, int mb, int nb, int bcol, int ti) {
         const int col = nb + r;
         double xb[DIM];
         if (EPI == EPI_COV) {
             const long bc = bcol < 0 ? 0 : bcol;
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) xb[c] = pb.XB[bc * DIM + c];
+            for (int c = 0; c < DIM; ++c) xb[c] = gld(pb.XB + bc * DIM + c);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -412,31 +440,34 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
+            else if (EPI == EPI_SUB) v = cin[ti][s] - acc[s];
             else if (EPI == EPI_COV) {
                 long xrow = row;
-                if (pb.idxA) { const int ia = pb.idxA[row]; xrow = ia; }
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (xrow < 0 ? 0 : xrow) * DIM, xb, kp.circular)) - acc[s];
+                if (pb.idxA) { const int ia = gldi(pb.idxA + row); xrow = ia; }
+                double xa[DIM];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) xa[c] = gld(pb.XA + (xrow < 0 ? 0 : xrow) * DIM + c);
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) - acc[s];
                 v = (bcol < 0 || xrow < 0) ? 0.0 : cv;
                 if (pb.sym_diag && row == col) v = (bcol < 0) ? 1.0 : v + pb.diag_add;
                 if (pb.rowmap) {
-                    const int op = pb.rowmap[row];
-                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                    const int op = gldi(pb.rowmap + row);
+                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
                 }
             } else {
-                v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+                v = (bcol < 0) ? 0.0 : gld(pb.Csrc + (long)row * pb.ldcs + col) - acc[s];
                 if (pb.rowmap) {
-                    const int op = pb.rowmap[row];
-                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                    const int op = gldi(pb.rowmap + row);
+                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
                 }
             }
-            *cp = v;
+            gst(cp, v);
         }
     };
-    emit(c00, m0, n0, bc0);
-    if (nv1) emit(c01, m0, n0 + 16, bc1);
-    if (mv1) emit(c10, m0 + 16, n0, bc0);
-    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1);
+    emit(c00, m0, n0, bc0, 0);
+    if (nv1) emit(c01, m0, n0 + 16, bc1, 1);
+    if (mv1) emit(c10, m0 + 16, n0, bc0, 2);
+    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
