@@ -426,40 +426,52 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
     const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
     int bc0 = n0 + r, bc1 = n0 + 16 + r;
     if (pb.idxB) { bc0 = gldi(pb.idxB + n0 + r); bc1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1; }
+    // COV / HOSTCOV: everything the epilogue reads per row and per column (gather indices, coordinates,
+    // the leaf's observed-row map) is fetched here in two rounds of independent loads; read inside the
+    // element loop each load sits behind the stores of the previous element and pays its own round trip
+    long xrow8[8];
+    int op8[8];
+    double xa8[8][DIM], xb2[2][DIM];
+    if (EPI == EPI_COV || EPI == EPI_HOSTCOV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = min(m0 + (e >> 2) * 16 + q + 4 * (e & 3), pb.M - 1);
+            xrow8[e] = pb.idxA ? (long)gldi(pb.idxA + row) : (long)row;
+            op8[e] = pb.rowmap ? gldi(pb.rowmap + row) : -1;
+        }
+        if (EPI == EPI_COV) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) xa8[e][c] = gld(pb.XA + (xrow8[e] < 0 ? 0 : xrow8[e]) * DIM + c);
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                xb2[0][c] = gld(pb.XB + (long)(bc0 < 0 ? 0 : bc0) * DIM + c);
+                xb2[1][c] = gld(pb.XB + (long)(bc1 < 0 ? 0 : bc1) * DIM + c);
+            }
+        }
+    }
     auto emit = [&](d4 acc, int mb, int nb, int bcol, int ti) {
         const int col = nb + r;
-        double xb[DIM];
-        if (EPI == EPI_COV) {
-            const long bc = bcol < 0 ? 0 : bcol;
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) xb[c] = gld(pb.XB + bc * DIM + c);
-        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = mb + q + 4 * s;
+            const int e8 = (ti >> 1) * 4 + s;
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = cin[ti][s] - acc[s];
             else if (EPI == EPI_COV) {
-                long xrow = row;
-                if (pb.idxA) { const int ia = gldi(pb.idxA + row); xrow = ia; }
-                double xa[DIM];
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) xa[c] = gld(pb.XA + (xrow < 0 ? 0 : xrow) * DIM + c);
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) - acc[s];
+                const long xrow = xrow8[e8];
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa8[e8], xb2[ti & 1], kp.circular)) - acc[s];
                 v = (bcol < 0 || xrow < 0) ? 0.0 : cv;
                 if (pb.sym_diag && row == col) v = (bcol < 0) ? 1.0 : v + pb.diag_add;
-                if (pb.rowmap) {
-                    const int op = gldi(pb.rowmap + row);
-                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
-                }
+                const int op = op8[e8];
+                if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
             } else {
                 v = (bcol < 0) ? 0.0 : gld(pb.Csrc + (long)row * pb.ldcs + col) - acc[s];
-                if (pb.rowmap) {
-                    const int op = gldi(pb.rowmap + row);
-                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
-                }
+                const int op = op8[e8];
+                if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
             }
             gst(cp, v);
         }
