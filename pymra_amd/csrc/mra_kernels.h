@@ -57,12 +57,12 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
 __device__ __forceinline__ d4 load_rowlane(const double* __restrict__ p, long ld, int r, int q) {
     const double* a = p + (long)r * ld + q;
     d4 v;
-    v[0] = a[0]; v[1] = a[4]; v[2] = a[8]; v[3] = a[12];
+    v[0] = gld(a); v[1] = gld(a + 4); v[2] = gld(a + 8); v[3] = gld(a + 12);
     return v;
 }
 __device__ __forceinline__ void store_rowlane(double* __restrict__ p, long ld, int r, int q, d4 v) {
     double* a = p + (long)r * ld + q;
-    a[0] = v[0]; a[4] = v[1]; a[8] = v[2]; a[12] = v[3];
+    gst(a, v[0]); gst(a + 4, v[1]); gst(a + 8, v[2]); gst(a + 12, v[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,8 +225,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
 
     int br0 = n0 + r, br1 = n0 + 16 + r;
     if (pb.idxB) {
-        br0 = pb.idxB[n0 + r];
-        br1 = nv1 ? pb.idxB[n0 + 16 + r] : -1;
+        br0 = gldi(pb.idxB + n0 + r);
+        br1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1;
     }
     const bool bz0 = br0 < 0, bz1 = (!nv1) || br1 < 0;
     d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
@@ -237,15 +237,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         long lda = pb.lda, ldb = pb.ldb;
         int K = pb.K;
         if (pb.nseg > 0) { const GemmSeg g = pb.segs[sg]; Ap = g.A; Bp = g.B; lda = g.lda; ldb = g.ldb; K = g.K; }
+        // unconditional global loads one K-step ahead of the MFMAs (rows that do not exist read a valid
+        // row and are zeroed by a select): branches around loads force s_waitcnt vmcnt(0) in the loop
         const double* a0p = Ap + (long)(m0 + r) * lda + 4 * q;
-        const double* a1p = a0p + 16 * lda;
+        const double* a1p = mv1 ? a0p + 16 * lda : a0p;
         const double* b0p = Bp + (long)(bz0 ? 0 : br0) * ldb + 4 * q;
         const double* b1p = Bp + (long)(bz1 ? 0 : br1) * ldb + 4 * q;
+        d4 na0 = zero, na1 = zero, nb0 = zero, nb1 = zero;
+        if (K > 0) { na0 = gld4(a0p); na1 = gld4(a1p); nb0 = gld4(b0p); nb1 = gld4(b1p); }
         for (int k0 = 0; k0 < K; k0 += 16) {
-            d4 a0 = *(const d4*)(a0p + k0);
-            d4 a1 = mv1 ? *(const d4*)(a1p + k0) : zero;
-            d4 b0 = bz0 ? zero : *(const d4*)(b0p + k0);
-            d4 b1 = bz1 ? zero : *(const d4*)(b1p + k0);
+            const d4 a0 = na0, a1 = mv1 ? na1 : zero, b0 = bz0 ? zero : nb0, b1 = bz1 ? zero : nb1;
+            const int kn = (k0 + 16 < K) ? k0 + 16 : k0;
+            na0 = gld4(a0p + kn); na1 = gld4(a1p + kn); nb0 = gld4(b0p + kn); nb1 = gld4(b1p + kn);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 c00 = mfma16(a0[j], b0[j], c00);
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         if (EPI == EPI_COV) {
             const long bc = bcol < 0 ? 0 : bcol;
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) xb[c] = pb.XB[bc * DIM + c];
+            for (int c = 0; c < DIM; ++c) xb[c] = gld(pb.XB + bc * DIM + c);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -270,22 +273,25 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : *cp) - acc[s];
+            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : gld(cp)) - acc[s];
             else if (EPI == EPI_COV) {
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(pb.XA + (long)row * DIM, xb, kp.circular)) - acc[s];
+                double xa[DIM];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) xa[c] = gld(pb.XA + (long)row * DIM + c);
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) - acc[s];
                 v = (bcol < 0) ? 0.0 : cv;
                 if (pb.rowmap) {
-                    const int op = pb.rowmap[row];
-                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                    const int op = gldi(pb.rowmap + row);
+                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
                 }
             } else {
-                v = (bcol < 0) ? 0.0 : pb.Csrc[(long)row * pb.ldcs + col] - acc[s];
+                v = (bcol < 0) ? 0.0 : gld(pb.Csrc + (long)row * pb.ldcs + col) - acc[s];
                 if (pb.rowmap) {
-                    const int op = pb.rowmap[row];
-                    if (op >= 0) pb.C2[(long)op * pb.ldc + col] = v + (op == col ? pb.diag_add : 0.0);
+                    const int op = gldi(pb.rowmap + row);
+                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
                 }
             }
-            *cp = v;
+            gst(cp, v);
         }
     };
     const int bc0 = pb.idxB ? br0 : n0 + r, bc1 = pb.idxB ? br1 : n0 + 16 + r;
@@ -623,10 +629,12 @@ __global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict_
             if (lane < 16) {
                 double* dp = pb.P + (long)(jb * 16 + lane) * pb.ld + jb * 16;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) dp[k] = a[k];
+                for (int k = 0; k < 16; k += 2) gst2(dp + k, d2{a[k], a[k + 1]});
                 double* ip = pb.invd + (long)jb * 256;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { sinv[lane][k] = m[k]; ip[lane * 16 + k] = m[k]; }
+                for (int k = 0; k < 16; ++k) sinv[lane][k] = m[k];
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) gst2(ip + lane * 16 + k, d2{m[k], m[k + 1]});
                 if (bad && lane == 0) atomicMax(err, pb.node + 1);
             }
         }
@@ -670,15 +678,17 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
         // ---- diagonal tile: left-looking update, then factor + invert
         {
             double* tp = P + (long)(jb * 16 + r) * ld + jb * 16 + 4 * q;
-            d4 acc = *(const d4*)tp;
-            d4 upd = zero;
+            d4 acc = gld4(tp);
+            d4 upd0 = zero, upd1 = zero;          // two chains: dependent f64 MFMAs issue every ~73 ns, independent ones every ~29 ns
             for (int kb = 0; kb < jb; ++kb) {
-                const d4 a = *(const d4*)(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
-                const d4 b = *(const d4*)(P + (long)(jb * 16 + r) * ld + kb * 16 + 4 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
+                const d4 a = gld4(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
+                const d4 b = gld4(P + (long)(jb * 16 + r) * ld + kb * 16 + 4 * q);
+                upd0 = mfma16(a[0], b[0], upd0);
+                upd1 = mfma16(a[1], b[1], upd1);
+                upd0 = mfma16(a[2], b[2], upd0);
+                upd1 = mfma16(a[3], b[3], upd1);
             }
-            acc -= upd;
+            acc -= upd0 + upd1;
             *(d4*)(sd + r * 16 + 4 * q) = acc;
         }
         __builtin_amdgcn_wave_barrier();
@@ -691,9 +701,9 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
                 double* dp = P + (long)(jb * 16 + lane) * ld + jb * 16;
                 double* ip2 = invd + (long)jb * 256;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) dp[k] = a[k];
+                for (int k = 0; k < 16; k += 2) gst2(dp + k, d2{a[k], a[k + 1]});
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { si[lane * 16 + k] = m[k]; ip2[lane * 16 + k] = m[k]; }
+                for (int k = 0; k < 16; k += 2) { *(d2*)(si + lane * 16 + k) = d2{m[k], m[k + 1]}; gst2(ip2 + lane * 16 + k, d2{m[k], m[k + 1]}); }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -701,19 +711,21 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
         // ---- rows below
         for (int ib = jb + 1; ib < nt; ++ib) {
             double* tp = P + (long)(ib * 16 + r) * ld + jb * 16 + 4 * q;
-            d4 acc = *(const d4*)tp;
-            d4 upd = zero;
+            d4 acc = gld4(tp);
+            d4 upd0 = zero, upd1 = zero;
             for (int kb = 0; kb < jb; ++kb) {
-                const d4 a = *(const d4*)(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
-                const d4 b = *(const d4*)(P + (long)(ib * 16 + r) * ld + kb * 16 + 4 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], b[j], upd);
+                const d4 a = gld4(P + (long)(jb * 16 + prow) * ld + kb * 16 + 4 * q);
+                const d4 b = gld4(P + (long)(ib * 16 + r) * ld + kb * 16 + 4 * q);
+                upd0 = mfma16(a[0], b[0], upd0);
+                upd1 = mfma16(a[1], b[1], upd1);
+                upd0 = mfma16(a[2], b[2], upd0);
+                upd1 = mfma16(a[3], b[3], upd1);
             }
-            acc -= upd;
-            d4 x = zero;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x = mfma16(ia[j], acc[j], x);
-            *(d4*)tp = x;
+            acc -= upd0 + upd1;
+            d4 x0 = mfma16(ia[0], acc[0], zero), x1 = mfma16(ia[1], acc[1], zero);
+            x0 = mfma16(ia[2], acc[2], x0);
+            x1 = mfma16(ia[3], acc[3], x1);
+            gst4(tp, x0 + x1);
         }
         __threadfence_block();          // this wave's stores before its own later loads (other lanes)
     }
@@ -806,7 +818,7 @@ __device__ __forceinline__ void stage_chunks(double* __restrict__ ldsb, int tota
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int e = e0 + g * (int)blockDim.x;
-            v[g] = *(const d2*)src(e < total ? e : total - 1);       // clamped: always a valid address
+            v[g] = gld2(src(e < total ? e : total - 1));             // clamped: always a valid address
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -865,40 +877,51 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
         double* xp = pb.X + (long)t * 16 * pb.ldx + (long)r * pb.ldx + 4 * q;
         d4 x[NTMAX];
         double ssq = 0.0;
+        // the whole row of tiles is fetched first (independent loads in flight together); read one
+        // tile at a time each load would wait behind the store of the previous tile
 #pragma unroll
         for (int jb = 0; jb < NTMAX; ++jb) {
             if (jb < nt) {
-                d4 acc;
                 if (t < pb.gtiles) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int gi = pb.gidx[jb * 16 + 4 * q + j];
-                        acc[j] = gi < 0 ? 0.0 : pb.gW[(long)gi * pb.gld + t * 16 + r];
+                        const int gi = gldi(pb.gidx + jb * 16 + 4 * q + j);
+                        x[jb][j] = gi < 0 ? 0.0 : gld(pb.gW + (long)gi * pb.gld + t * 16 + r);
                     }
                 } else {
-                    acc = *(const d4*)(xp + jb * 16);
+                    x[jb] = gld4(xp + jb * 16);
                 }
-                d4 upd = zero;
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < NTMAX; ++jb) {
+            if (jb < nt) {
+                d4 acc = x[jb];
+                // two accumulators: a dependent f64 MFMA issues every ~73 ns, an independent one every ~29 ns
+                d4 upd0 = zero, upd1 = zero;
 #pragma unroll
                 for (int kb = 0; kb < jb; ++kb) {
                     const d4 a = *(const d4*)(lds + (jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) upd = mfma16(a[j], x[kb][j], upd);
+                    upd0 = mfma16(a[0], x[kb][0], upd0);
+                    upd1 = mfma16(a[1], x[kb][1], upd1);
+                    upd0 = mfma16(a[2], x[kb][2], upd0);
+                    upd1 = mfma16(a[3], x[kb][3], upd1);
                 }
-                acc -= upd;
+                if (jb > 0) acc -= upd0 + upd1;
                 const d4 ia = *(const d4*)(lds + (ntri + jb) * 256 + prow * 16 + 4 * q);
-                d4 xx = zero;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], acc[j], xx);
+                d4 xx0 = mfma16(ia[0], acc[0], zero), xx1 = mfma16(ia[1], acc[1], zero);
+                xx0 = mfma16(ia[2], acc[2], xx0);
+                xx1 = mfma16(ia[3], acc[3], xx1);
+                const d4 xx = xx0 + xx1;
                 x[jb] = xx;
-                *(d4*)(xp + jb * 16) = xx;
+                gst4(xp + jb * 16, xx);
                 ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
             }
         }
         if (pb.var && t >= pb.var_tile0) {
             ssq += __shfl_xor(ssq, 16, 64);
             ssq += __shfl_xor(ssq, 32, 64);
-            if (q == 0) pb.var[(long)(t - pb.var_tile0) * 16 + r] += pb.var_sign * ssq;
+            if (q == 0) { double* vp = pb.var + (long)(t - pb.var_tile0) * 16 + r; gst(vp, gld(vp) + pb.var_sign * ssq); }
         }
     }
 }
@@ -1075,7 +1098,7 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
         const int op = ar.obs_pos[myrow];
         if (op >= 0 && q == 0) {
             const int lf = ar.tile_leaf[t];
-            ar.leaf_ut[lf][(long)ar.ut_yrow * ar.leaf_nop[lf] + op] = ar.y[myrow];
+            gst(ar.leaf_ut[lf] + (long)ar.ut_yrow * ar.leaf_nop[lf] + op, ar.y[myrow]);
         }
     }
 }
@@ -1102,7 +1125,7 @@ __device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, in
         for (int jb = 0; jb < CWT; ++jb) {
             const d4 v = w[m][jb];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ut[(long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op] = v[j];
+            for (int j = 0; j < 4; ++j) gst(ut + (long)(ar.ut_off[m] + jb * 16 + 4 * q + j) * nop + op, v[j]);
         }
     }
     return ssq;
