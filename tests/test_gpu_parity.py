@@ -378,3 +378,45 @@ def test_plan_reuse_for_mle(hip):
     full = base.reevaluate(lambda a, b: mt.Matern32(a, b, l=0.3, sig=1.0), want_predict=True)
     assert abs(full[0, 0] - float(cs["g"]["lik"])) <= 1e-9 * abs(float(cs["g"]["lik"]))
     assert np.max(np.abs(np.asarray(base.predict()[0]).ravel() - cs["g"]["mean"])) < 1e-7
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_random_geometries(hip, seed):
+    """Seeded random problems away from the benchmark geometry: rectangular grids, jittered and fully
+    scattered 2-D locations, every kernel family, r0 that is not a multiple of 16, shallow and deep trees,
+    sparse and dense observations.  HIP path vs the level-wise oracle on the same tree."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    rng = np.random.RandomState(1000 + seed)
+    np.random.seed(seed)                      # the 2-D knot draws of the tree replay use the global RNG
+    nx, ny = int(rng.randint(24, 72)), int(rng.randint(24, 72))
+    kind = seed % 3
+    if kind == 0:
+        locs = mt.genLocations2d(Nx=nx, Ny=ny)
+    elif kind == 1:
+        locs = mt.genLocations2d(Nx=nx, Ny=ny) + rng.uniform(-0.3, 0.3, size=(nx * ny, 2)) / max(nx, ny)
+    else:
+        locs = rng.uniform(0, 1, size=(nx * ny, 2))
+    N = len(locs)
+    r = int(rng.choice([5, 8, 16, 20, 32]))
+    M = int(rng.randint(1, 4))
+    frac = float(rng.choice([0.1, 0.4, 0.9]))
+    y = rng.normal(size=(N, 1))
+    y_obs = np.where(rng.uniform(size=(N, 1)) < frac, y, np.nan)
+    specs = [mt.KernelSpec(mt.KIND_EXP, 0.2), mt.KernelSpec(mt.KIND_MATERN32, 0.15, 1.3), mt.KernelSpec(mt.KIND_MATERN52, 0.2, 0.7),
+             mt.KernelSpec(mt.KIND_GAUSSIAN, 0.05, 1.0), mt.KernelSpec(mt.KIND_MATERN32, 0.4, 1.0, 2.5)]
+    spec = specs[seed % len(specs)]
+    R = float(rng.choice([1e-3, 5e-2, 0.5]))
+    topo = build_topology(locs, r, M, 4)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=R))
+    pl, lik, mean, var = run_hip(hip, cs)
+    ref = run_levelwise(topo, locs, spec, y_obs, R)
+    assert abs(lik - ref["lik"]) <= 1e-9 * max(1.0, abs(ref["lik"]))
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-8
+    assert np.max(np.abs(np.sqrt(np.maximum(var, 0)) - ref["sd"])) < 1e-7
+    # likelihood-only rerun on the same plan
+    pl.run(True, False)
+    d, u = pl.likelihood()
+    assert abs(d + u - lik) <= 1e-11 * max(1.0, abs(lik))
+    pl.close()
