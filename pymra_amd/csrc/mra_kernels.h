@@ -948,6 +948,7 @@ struct CascadeLevel {
     const double* invd;   // [node][cwt][256]
 };
 struct CascadeArgs {
+    int ycol;               // row mode: column of W's y block to initialise (-1: leave it)
     CascadeLevel lev[8];
     const double* X;          // coordinates of all rows [P][DIM]
     double* W;                // FULL: whitened basis, ldw
@@ -1093,6 +1094,11 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
         if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
+    }
+    if (ar.ycol >= 0) {                 // the 16-wide y block of W: y (0 where missing) in its first column
+        const double yy = ar.y[myrow];
+        const d4 yt = {(q == 0 && isfinite(yy)) ? yy : 0.0, 0.0, 0.0, 0.0};
+        *(d4*)(ar.W + myrow * ar.ldw + ar.ycol + 4 * q) = yt;
     }
     if (ar.obs_pos) {
         const int op = ar.obs_pos[myrow];

@@ -778,6 +778,7 @@ static double kernel_cov0(const mra_plan* pl) { return pl->kp.amp; }   // C(x,x)
 static void run_prior_fused(mra_plan* pl) {
     const int cw = pl->cw[0];
     CascadeArgs base{};
+    base.ycol = -1;
     for (int m = 0; m < pl->NL; ++m) {
         base.lev[m].kx = pl->fl[m].kx.p; base.lev[m].kvalid = pl->fl[m].kvalid.p; base.lev[m].Wk = pl->fl[m].Wk.p;
         base.lev[m].L = pl->lev[m].Lp.p; base.lev[m].invd = pl->lev[m].invP.p;
@@ -803,6 +804,7 @@ static void run_prior_fused(mra_plan* pl) {
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1;
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
+        ar.ycol = pl->Ka; ar.y = pl->y.p;
         if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
             ar.obs_pos = pl->obs_pos.p; ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p;
             ar.y = pl->y.p;
@@ -1007,7 +1009,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     HIP_TRY(hipMemsetAsync(pl->errflag.p, 0, sizeof(int), pl->stream));
     const bool pred = flags & MRA_RUN_PREDICT;
     phase_mark(pl, 0);
-    {
+    if (!(pl->regular && pl->use_fused && !pl->host_cov)) {        // the fused prior cascade writes the y block itself
         KTimer kt(pl, KF_MISC, 0);
         const long n = pl->P * MRA_YB;
         hipLaunchKernelGGL(k_init_yblock, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pl->stream, pl->W.p,
