@@ -231,6 +231,20 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
     const bool bz0 = br0 < 0, bz1 = (!nv1) || br1 < 0;
     d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
     const d4 zero = {0, 0, 0, 0};
+    // SUB: the C tile is fetched before the products (independent loads in flight together), not element
+    // by element behind the stores of the epilogue
+    d4 cin[4] = {zero, zero, zero, zero};
+    if (EPI == EPI_SUB) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int mb = m0 + (t4 >> 1) * 16, nb = n0 + (t4 & 1) * 16;
+            const int col = nb + r;
+            if (mb < pb.M && nb < pb.N && !(pb.zc > 0 && col >= pb.zc)) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
+            }
+        }
+    }
     const int nseg = pb.nseg > 0 ? pb.nseg : 1;
     for (int sg = 0; sg < nseg; ++sg) {
         const double *Ap = pb.A, *Bp = pb.B;
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         }
     }
     // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
-    auto emit = [&](d4 acc, int mb, int nb, int bcol) {
+    auto emit = [&](d4 acc, int mb, int nb, int bcol, int ti) {
         const int col = nb + r;
         double xb[DIM];
         if (EPI == EPI_COV) {
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = ((pb.zc > 0 && col >= pb.zc) ? 0.0 : gld(cp)) - acc[s];
+            else if (EPI == EPI_SUB) v = cin[ti][s] - acc[s];
             else if (EPI == EPI_COV) {
                 double xa[DIM];
 #pragma unroll
@@ -295,10 +309,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         }
     };
     const int bc0 = pb.idxB ? br0 : n0 + r, bc1 = pb.idxB ? br1 : n0 + 16 + r;
-    emit(c00, m0, n0, bc0);
-    if (nv1) emit(c01, m0, n0 + 16, bc1);
-    if (mv1) emit(c10, m0 + 16, n0, bc0);
-    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1);
+    emit(c00, m0, n0, bc0, 0);
+    if (nv1) emit(c01, m0, n0 + 16, bc1, 1);
+    if (mv1) emit(c10, m0 + 16, n0, bc0, 2);
+    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
