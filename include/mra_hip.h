@@ -128,7 +128,9 @@ int mra_get_predict(mra_plan *plan, double *mean_perm, double *var_perm);
 int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int64_t *n_avail);
 
 /* Per-phase device milliseconds of the last mra_run (hipEvent deltas on the plan's stream):
- * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written. */
+ * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written.
+ * The four phase entries are measured only while MRA_OPT_KERNEL_TIMING is on (0 otherwise): an event
+ * between dependent launches costs a few microseconds of stream time; the total is always measured. */
 int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 
 /* Kernel-level timing: with option MRA_OPT_KERNEL_TIMING on, every launch of mra_run is bracketed by

@@ -1577,7 +1577,7 @@ __global__ void k_extract_mean(const double* __restrict__ W, long ldw, int Ka, d
 // error flag} is the one record the host reads back
 __global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dnode, int n, double* __restrict__ out,
                                                    const double* __restrict__ up = nullptr, const double* __restrict__ below = nullptr,
-                                                   const int* __restrict__ err = nullptr) {
+                                                   const int* err = nullptr) {
     __shared__ double part[256];
     double s = 0.0;
     const int chunk = (n + 255) / 256;
@@ -1593,6 +1593,7 @@ __global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dn
             out[1] = *up;
             out[2] = below ? *below : 0.0;
             out[3] = (double)(*err);
+            *const_cast<int*>(err) = 0;          // ready for the next pass (no memset launch per run)
         }
     }
 }

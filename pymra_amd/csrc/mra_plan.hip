@@ -251,6 +251,7 @@ static void build_static(mra_plan* pl) {
     pl->dnode.alloc(pl->n_nodes);
     pl->scal.alloc(4);
     pl->errflag.alloc(1);
+    HIP_TRY(hipMemset(pl->errflag.p, 0, sizeof(int)));       // k_sum_dnode reads it and clears it again at the end of every pass
     HIP_TRY(hipMemset(pl->W.p, 0, pl->W.n * sizeof(double)));
     HIP_TRY(hipMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
     HIP_TRY(hipMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
@@ -852,7 +853,9 @@ static void run_predict_fused(mra_plan* pl) {
     else launch_predict_cascade<4, 4>(pl, ar, lds);
 }
 
-static void phase_mark(mra_plan* pl, int k) { hipEventRecord(pl->ev[k], pl->stream); }
+// events 0 and 5 bracket every pass; the four inner phase boundaries are recorded only with kernel timing on
+// (each hipEventRecord between dependent launches leaves a ~6 us gap on the stream)
+static void phase_mark(mra_plan* pl, int k) { if (k == 0 || k == 5 || pl->ktiming) hipEventRecord(pl->ev[k], pl->stream); }
 
 static void run_front_level(mra_plan* pl, int m) {
     LevelData& lv = pl->lev[m];
@@ -969,7 +972,8 @@ static void finish_run(mra_plan* pl) {
     float ms;
     for (int k = 0; k < 4; ++k) {
         static const int a[4] = {0, 1, 2, 3}, b[4] = {1, 2, 3, 4};
-        hipEventElapsedTime(&ms, pl->ev[a[k]], pl->ev[b[k]]);
+        ms = 0.f;
+        if (pl->ktiming) hipEventElapsedTime(&ms, pl->ev[a[k]], pl->ev[b[k]]);
         pl->phase_ms[k] = ms;
     }
     hipEventElapsedTime(&ms, pl->ev[0], pl->ev[5]);
@@ -1006,7 +1010,6 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     HIP_TRY(hipSetDevice(pl->device));
     pl->run_flags = flags;
     for (int k = 0; k < KF_COUNT; ++k) pl->kstat[k] = mra_plan::KStat();
-    HIP_TRY(hipMemsetAsync(pl->errflag.p, 0, sizeof(int), pl->stream));
     const bool pred = flags & MRA_RUN_PREDICT;
     phase_mark(pl, 0);
     if (!(pl->regular && pl->use_fused && !pl->host_cov)) {        // the fused prior cascade writes the y block itself
