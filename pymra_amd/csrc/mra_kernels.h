@@ -962,6 +962,7 @@ struct CascadeLevel {
     const double* invd;   // [node][cwt][256]
 };
 struct CascadeArgs {
+    int knot_threads;       // host side only: workgroup size of a knot-mode launch
     int ycol;               // row mode: column of W's y block to initialise (-1: leave it)
     CascadeLevel lev[8];
     const double* X;          // coordinates of all rows [P][DIM]
@@ -1087,7 +1088,7 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
     const d4 zero = {0, 0, 0, 0};
     if (ar.knot_mode) {
         const int mo = ar.mlast + 1;
-        const int slotk = chain[mo];
+        const int slotk = ar.tile_chain[t * 8 + mo];       // the tile's own node (a workgroup holds a family of siblings)
         const int krow = ar.tile_knot0[t] + r;
         double* o = ar.Wk_out + ((long)slotk * CW + krow) * (mo * CW);
 #pragma unroll
@@ -1228,19 +1229,20 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
         if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
     }
     if (ar.knot_mode && ar.Lp_out) {
-        // ---- the node's kInv, factor and inverted diagonal blocks, still in this launch
+        // ---- kInv, factor and inverted diagonal blocks of every node of the workgroup, still in this launch
         constexpr int CW = CWT * 16;
-        double* s_sd = lds;            // the staged operands are dead by now: reuse the dynamic LDS as scratch
-        double* s_si = lds + 288;      // s_sd: 272 doubles (tile + exchange column of chol16_inv)
+        constexpr int NT2 = CWT * (CWT + 1) / 2;
         const int mo = ar.mlast + 1;
-        const int slotk = chain[mo];
         const int Kw = mo * CW;
-        const double* Wk = ar.Wk_out + (long)slotk * CW * Kw;
-        const double* kx = ar.lev[mo].kx + (long)slotk * CW * DIM;
-        double* Lp = ar.Lp_out + (long)slotk * CW * CW;
+        const int nnode = nt_wg / CWT;
         const d4 zero = {0, 0, 0, 0};
         __syncthreads();                                  // every wave's Wk rows are in global memory
-        for (int idx = wave; idx < CWT * (CWT + 1) / 2; idx += nwave) {
+        for (int w = wave; w < nnode * NT2; w += nwave) {
+            const int ni = w / NT2, idx = w - ni * NT2;
+            const int slotk = ar.tile_chain[(t0 + (long)ni * CWT) * 8 + mo];
+            const double* Wk = ar.Wk_out + (long)slotk * CW * Kw;
+            const double* kx = ar.lev[mo].kx + (long)slotk * CW * DIM;
+            double* Lp = ar.Lp_out + (long)slotk * CW * CW;
             int ib = 0;
             while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
             const int jb = idx - ib * (ib + 1) / 2;
@@ -1261,9 +1263,14 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             *(d4*)(Lp + (long)(ib * 16 + r) * CW + jb * 16 + 4 * q) = res;
         }
         __syncthreads();
-        if (wave == 0) {
+        // one wave per node; the staged operands are dead by now: the dynamic LDS is reused as per-wave scratch
+        // (272 doubles tile + exchange column of chol16_inv, 256 doubles inverse block)
+        for (int ni = wave; ni < nnode; ni += nwave) {
+            const int slotk = ar.tile_chain[(t0 + (long)ni * CWT) * 8 + mo];
+            double* s_sd = lds + wave * 576;
+            double* s_si = s_sd + 288;
             bool bad = false;
-            chol_wave_body(Lp, CW, CWT, ar.invd_out + (long)slotk * CWT * 256, s_sd, s_si, lane, bad);
+            chol_wave_body(ar.Lp_out + (long)slotk * CW * CW, CW, CWT, ar.invd_out + (long)slotk * CWT * 256, s_sd, s_si, lane, bad);
             if (bad && lane == 0) atomicMax(ar.err, 1000000 + slotk);
         }
     }

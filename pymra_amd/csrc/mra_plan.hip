@@ -179,6 +179,7 @@ struct mra_plan {
         DevVec<GemmProb> gKinv;
         DevVec<long> kt_wg0;
         long n_ktiles = 0, n_kwg = 0;
+        int k_threads = 256;        // workgroup size of the level's knot launch (512 when sibling families share a workgroup)
     };
     std::vector<FusedLevel> fl;
     DevVec<long> ft_row0, ft_wg0;
@@ -446,7 +447,14 @@ static void build_static(mra_plan* pl) {
                 for (int c = 0; c < cw; ++c) kv[sl * cw + c] = c < rk ? 1 : 0;
                 int ch[8];
                 chain_of(i, ch);
-                wg0.push_back((long)knot0.size()); wgn.push_back(cw / 16);
+                // one workgroup per family of siblings (same ancestor chain: the staged operands are shared),
+                // as long as it stays within 8 row tiles (one per wave on the level-by-level staging path)
+                // (only on levels with many nodes, where workgroups run in several rounds per CU: on small levels
+                // - the levels of a sharded rank - the longer per-workgroup chain costs more than it saves)
+                const bool same_family = nn >= 512 && sl > 0 && pl->parent[i] >= 0 && pl->parent[i] == pl->parent[lv.nodes[sl - 1]] &&
+                                         !wgn.empty() && wgn.back() + cw / 16 <= 8;
+                if (same_family) wgn.back() += cw / 16;
+                else { wg0.push_back((long)knot0.size()); wgn.push_back(cw / 16); }
                 for (int tt = 0; tt < cw / 16; ++tt) {
                     for (int r = 0; r < 16; ++r) {
                         const int c = tt * 16 + r;
@@ -459,6 +467,8 @@ static void build_static(mra_plan* pl) {
             f.kvalid.upload(kv); f.kt_rows.upload(rows); f.kt_chain.upload(chain); f.kt_knot0.upload(knot0);
             f.n_ktiles = (long)knot0.size();
             f.kt_wg0.upload(wg0); f.kt_wgn.upload(wgn); f.n_kwg = (long)wg0.size();
+            f.k_threads = 256;
+            for (int v : wgn) if (v > 4) f.k_threads = 512;
             {
                 // kInv of every node of the level: kernel(knots, knots) - Wk Wk^T as one batched COV product
                 std::vector<GemmProb> gk(nn);
@@ -744,11 +754,11 @@ static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
         attr = true;
     }
     if (pl->cascade_stage_all)
-        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 512),
-                           std::max<size_t>(pl->cascade_lds_all, 8192), pl->stream, ar, pl->kp);
+        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? ar.knot_threads : 512),
+                           std::max<size_t>(pl->cascade_lds_all, 40960), pl->stream, ar, pl->kp);
     else
-        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? 256 : 64 * pl->cascade_wpw),
-                           std::max<size_t>(pl->cascade_lds, 8192), pl->stream, ar, pl->kp);
+        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? ar.knot_threads : 64 * pl->cascade_wpw),
+                           std::max<size_t>(pl->cascade_lds, 40960), pl->stream, ar, pl->kp);
 }
 template <int CWT, int NLMAX>
 static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
@@ -791,7 +801,7 @@ static void run_prior_fused(mra_plan* pl) {
         LevelData& lv = pl->lev[m];
         KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol);
         CascadeArgs ar = base;
-        ar.knot_mode = 1; ar.mlast = m - 1; ar.n_wg = pl->fl[m].n_kwg;
+        ar.knot_mode = 1; ar.mlast = m - 1; ar.n_wg = pl->fl[m].n_kwg; ar.knot_threads = pl->fl[m].k_threads;
         ar.wg_tile0 = pl->fl[m].kt_wg0.p; ar.wg_ntiles = pl->fl[m].kt_wgn.p;
         ar.tile_rows = pl->fl[m].kt_rows.p; ar.tile_chain = pl->fl[m].kt_chain.p; ar.tile_knot0 = pl->fl[m].kt_knot0.p;
         ar.Wk_out = pl->fl[m].Wk.p;
