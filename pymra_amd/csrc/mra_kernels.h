@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
                 for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
             }
         }
+        c00 = -cin[0]; c01 = -cin[1]; c10 = -cin[2]; c11 = -cin[3];     // the epilogue writes -acc = C_in - A B^T
     }
     const int nseg = pb.nseg > 0 ? pb.nseg : 1;
     for (int sg = 0; sg < nseg; ++sg) {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = cin[ti][s] - acc[s];
+            else if (EPI == EPI_SUB) v = -acc[s];
             else if (EPI == EPI_COV) {
                 double xa[DIM];
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
 #define GL_PF 2           /* K-steps the global loads run ahead (register sets); even */
 
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
     __shared__ __attribute__((aligned(16))) double sA[2][64 * GL_LDS_LD];
     __shared__ __attribute__((aligned(16))) double sB[2][64 * GL_LDS_LD];
     unsigned prob_i, wg_i;
@@ -380,6 +381,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
                 for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
             }
         }
+        // ... and goes straight into the accumulators (negated; the epilogue writes -acc = C_in - A B^T): the
+        // tile then costs no registers during the K loop (32 VGPRs = one wave per SIMD of occupancy)
+        c00 = -cin[0]; c01 = -cin[1]; c10 = -cin[2]; c11 = -cin[3];
     }
     *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = a_ok ? ra[0] : zero;
     *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = b_ok ? rb[0] : zero;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_lds(const GemmProb* __restrict_
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = cin[ti][s] - acc[s];
+            else if (EPI == EPI_SUB) v = -acc[s];
             else if (EPI == EPI_COV) {
                 const long xrow = xrow8[e8];
                 const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa8[e8], xb2[ti & 1], kp.circular)) - acc[s];
