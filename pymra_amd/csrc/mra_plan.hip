@@ -1089,7 +1089,9 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                     const size_t ns = pl->n_trsm_small;
                     const int mts = pred ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
                     if (ns) launch_trsm2(pl, base, ns, pl->trsm_small_nt, mts, mts);
-                    if (nl > ns) launch_trsm2(pl, base + ns, nl - ns, ntl, mt, mt);
+                    // the few leaves with more than 128 observations: several workgroups per leaf when they are few
+                    // (one leaf per workgroup would put a single 65 us workgroup on the critical path)
+                    if (nl > ns) launch_trsm2(pl, base + ns, nl - ns, ntl, mt, (nl - ns) < 512 ? 4 : mt);
                 }
                 else launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
             } else {
