@@ -136,7 +136,8 @@ struct mra_plan {
     int reduce_level = -1;
     // device data
     DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag;
-    double* host_res = nullptr;      // pinned {d, u, below, err} record of the last pass
+    double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
+    double* host_res_dev = nullptr;  // the same memory as the device sees it
     DevVec<int> errflag, knot_idx, row_leaf;
     DevVec<long> knots_dev;
     std::vector<long> knot_idx_off;      // per node offset into knot_idx (padded to cw)
@@ -965,15 +966,18 @@ static void finish_run(mra_plan* pl) {
             const LevelData& lr = pl->lev[pl->reduce_level];
             if (lr.F.n) below = lr.F.p + (lr.F.n - 16);
         }
-        hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->scal.p, up, below, pl->errflag.p);
+        // the 32-byte record {d, u, log-det carried by the reduce level, error flag} is written by the kernel straight
+        // into pinned host memory (no copy command, no gap after the last launch)
+        if (!pl->host_res) {
+            HIP_TRY(hipHostMalloc((void**)&pl->host_res, 4 * sizeof(double), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&pl->host_res_dev, pl->host_res, 0));
+        }
+        hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->host_res_dev, up, below, pl->errflag.p);
         if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov))
             hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
                                pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
     }
     phase_mark(pl, 5);
-    // one 32-byte record back to the host: {d, u, log-det carried by the reduce level, error flag}
-    if (!pl->host_res) HIP_TRY(hipHostMalloc((void**)&pl->host_res, 4 * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(pl->host_res, pl->scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, pl->stream));
     HIP_TRY(hipStreamSynchronize(pl->stream));
     HIP_TRY(hipGetLastError());
     const int errv = (int)pl->host_res[3];
