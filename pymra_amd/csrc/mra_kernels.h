@@ -217,9 +217,18 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int tn = (pb.N + 31) >> 5, tm = (pb.M + 31) >> 5;
     const long tile = (long)wg_i * 4 + wave;
-    if (tile >= (long)tm * tn) return;
-    const int mt = (int)(tile / tn), nt = (int)(tile % tn);
-    if (pb.lower && nt > mt) return;
+    int mt, nt;
+    if (pb.lower) {
+        // lower-triangular products (SYRK, Schur): only the tm(tm+1)/2 tiles on or below the diagonal are
+        // enumerated (the host sizes G for them), so no workgroup is launched just to exit
+        if (tile >= (long)tm * (tm + 1) / 2) return;
+        mt = 0;
+        while ((long)(mt + 1) * (mt + 2) / 2 <= tile) ++mt;
+        nt = (int)(tile - (long)mt * (mt + 1) / 2);
+    } else {
+        if (tile >= (long)tm * tn) return;
+        mt = (int)(tile / tn); nt = (int)(tile % tn);
+    }
     const int m0 = mt << 5, n0 = nt << 5;
     const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
 

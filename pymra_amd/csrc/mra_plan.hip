@@ -689,16 +689,17 @@ struct KTimer {
     }
 };
 
-static inline unsigned gemm_grid_x(long M, long N) {
+static inline unsigned gemm_grid_x(long M, long N, bool lower_tri) {
     const long tm = (M + 31) / 32, tn = (N + 31) / 32;
-    return (unsigned)((tm * tn + 3) / 4);
+    return (unsigned)(((lower_tri ? tm * (tm + 1) / 2 : tm * tn) + 3) / 4);
 }
 
 template <int EPI>
-static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true) {
+// lower_tri: every problem of the batch has .lower set and M == N (direct kernel only)
+static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true, bool lower_tri = false) {
     if (!nprob || maxM <= 0 || maxN <= 0) return;
     const bool lds = pl->gemm_lds && allow_lds;
-    const unsigned gx = lds ? (unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)) : gemm_grid_x(maxM, maxN);
+    const unsigned gx = lds ? (unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)) : gemm_grid_x(maxM, maxN, lower_tri);
     const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
     // 1-D grid, XCD-aware (xcd_problem_tile): gx workgroups per problem, problems rounded up to 8
     const size_t chunk = (size_t)std::max<long>(8, ((0x7fffffffL / (long)gx) / 8) * 8);
@@ -873,7 +874,7 @@ static void run_front_level(mra_plan* pl, int m) {
     const size_t nn = lv.nodes.size();
     if (!nn) return;
     { KTimer kt(pl, KF_FRONT_CHOL, lv.fl_fchol); launch_panel(pl, lv.gFrontChol.p, nn); }
-    { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na, false); }
+    { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na, false, true); }
 }
 
 static void run_assemble_level(mra_plan* pl, int m, bool with_identity) {
@@ -903,7 +904,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
             if (pl->direct_parent && m == pl->NL - 1) {
                 const LevelData& lvp = pl->lev[m];
                 KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk);
-                launch_gemm<EPI_SET>(pl, pl->gParentSyrk.p, lvp.nodes.size(), lvp.nf, lvp.nf, false);
+                launch_gemm<EPI_SET>(pl, pl->gParentSyrk.p, lvp.nodes.size(), lvp.nf, lvp.nf, false, true);
             } else
             run_assemble_level(pl, m, !is_red);
             if (is_red) {
@@ -1104,7 +1105,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         }
         pl->direct_parent = pl->parent_syrk && pl->reduce_level != pl->NL - 1;
         if (!pl->direct_parent) ensure_gt(pl);
-        if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false); }
+        if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false, true); }
         if (pred) {
             if (!fused || pl->leaf_max_nop / 16 > 12) {
                 KTimer kt(pl, KF_MISC, 0);
