@@ -116,7 +116,10 @@ struct LevelData {
 
 struct mra_plan {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // the pass; carries the chain of small dependent launches and the all-reduce (high priority)
+    hipStream_t stream2 = nullptr;       // side stream: the leaf update runs here, beside the front chain / all-reduce (low priority)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;           // work on stream2 that the predictive pass has to wait for
     std::string err;
     // topology (host)
     long P = 0;
@@ -931,6 +934,10 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
         run_front_level(pl, m);
     }
     phase_mark(pl, 3);
+    if (pl->side_pending) {                                 // join: the leaf update on the side stream
+        HIP_TRY(hipStreamWaitEvent(pl->stream, pl->ev_join, 0));
+        pl->side_pending = false;
+    }
     const bool fusedp = pl->regular && pl->use_fused && !pl->host_cov;
     if ((pl->run_flags & MRA_RUN_PREDICT) && fusedp) run_predict_fused(pl);
     if ((pl->run_flags & MRA_RUN_PREDICT) && !fusedp) {
@@ -1107,6 +1114,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         if (!pl->direct_parent) ensure_gt(pl);
         if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false, true); }
         if (pred) {
+            // fork: everything below only feeds the predictive pass.  With per-kernel timing on it stays on the main
+            // stream so that the hipEvent brackets measure one kernel at a time.
+            const bool side = !pl->ktiming;
+            hipStream_t main_stream = pl->stream;
+            if (side) {
+                HIP_TRY(hipEventRecord(pl->ev_fork, main_stream));
+                HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->ev_fork, 0));
+                pl->stream = pl->stream2;                    // the launch helpers below use pl->stream
+            }
             if (!fused || pl->leaf_max_nop / 16 > 12) {
                 KTimer kt(pl, KF_MISC, 0);
                 double cov0 = 0.0;
@@ -1124,6 +1140,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                                    pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
             }
             { KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update); launch_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl, pl->leaf_max_rows, pl->leaf_max_na); }
+            if (side) {
+                pl->stream = main_stream;
+                HIP_TRY(hipEventRecord(pl->ev_join, pl->stream2));
+                pl->side_pending = true;
+            }
         }
     }
     phase_mark(pl, 2);
@@ -1172,7 +1193,18 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
         pl->knot_rows.assign(t->knot_rows, t->knot_rows + pl->knot_ptr.back());
         pl->cw.assign(t->cw, t->cw + t->n_levels);
         if (pl->level_ptr[0] != 0 || pl->level_ptr.back() != t->n_nodes) throw MraError(MRA_ERR_INVALID, "level_ptr inconsistent");
-        HIP_TRY(hipStreamCreate(&pl->stream));
+        {
+            // The leaf update (one large GEMM) and [parent SYRK -> front Cholesky/Schur chain -> all-reduce of a sharded run]
+            // only meet again in the predictive cascade: they are issued on two streams, so the collective and the
+            // latency-bound chain never wait behind the update.  (On one GPU the update keeps every SIMD's register file
+            // full and the pass time does not change; the point is the sharded run.)
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&pl->stream, hipStreamDefault, hi));
+            HIP_TRY(hipStreamCreateWithPriority(&pl->stream2, hipStreamDefault, lo));
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+        }
         for (int k = 0; k < 6; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
         build_static(pl);
         *out = pl;
@@ -1198,6 +1230,9 @@ int mra_plan_destroy(mra_plan* pl) {
     }
     for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
     if (pl->stream) hipStreamDestroy(pl->stream);
+    if (pl->stream2) hipStreamDestroy(pl->stream2);
+    if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
+    if (pl->ev_join) hipEventDestroy(pl->ev_join);
     if (pl->host_res) hipHostFree(pl->host_res);
     delete pl;
     return MRA_OK;
