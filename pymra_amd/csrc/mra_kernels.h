@@ -347,7 +347,10 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     if (pb.lower && nt > mt) return;
     const int M0 = mt << 6, N0 = nt << 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves
+    // wave tiles: 2 x 2 waves of 32 x 32; when at most 32 columns are left in this column tile (N = 224: the fourth
+    // tile) the waves are stacked 4 x 1 with 16 x 32 each instead of leaving two of them idle
+    const bool narrow = (pb.N - N0) <= 32;
+    const int wr0 = narrow ? wave * 16 : (wave >> 1) * 32, wc0 = narrow ? 0 : (wave & 1) * 32;
     // ---- staging role: thread -> (row, 32-byte chunk) of A and of B
     const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
     bool a_ok = (M0 + srow) < pb.M;
@@ -378,14 +381,14 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     }
     // SUB: the C tile this wave is going to update is fetched now, not after the K loop (sixteen
     // dependent 8-byte loads at the tail of every workgroup cost ~0.27 ms of the leaf update)
-    const int pm0 = M0 + wm * 32, pn0 = N0 + wn * 32;
+    const int pm0 = M0 + wr0, pn0 = N0 + wc0;
     d4 cin[4] = {zero, zero, zero, zero};
     if (EPI == EPI_SUB && pm0 < pb.M && pn0 < pb.N) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const int mb = pm0 + (t4 >> 1) * 16, nb = pn0 + (t4 & 1) * 16;
             const int col = nb + r;
-            if (mb < pb.M && nb < pb.N && !(pb.zc > 0 && col >= pb.zc)) {
+            if (mb < pb.M && nb < pb.N && !(narrow && t4 >= 2) && !(pb.zc > 0 && col >= pb.zc)) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
             }
@@ -397,11 +400,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = a_ok ? ra[0] : zero;
     *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = b_ok ? rb[0] : zero;
     __syncthreads();
-    const int arow0 = (wm * 32 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
-    const int brow0 = (wn * 32 + r) * GL_LDS_LD + 4 * q, brow1 = brow0 + 16 * GL_LDS_LD;
+    const int arow0 = (wr0 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
+    const int brow0 = (wc0 + r) * GL_LDS_LD + 4 * q, brow1 = brow0 + 16 * GL_LDS_LD;
     // which of this wave's four 16x16 sub-tiles exist (wave-uniform): padded sub-tiles issue no MFMA
-    const bool w_m0 = (M0 + wm * 32) < pb.M, w_m1 = (M0 + wm * 32 + 16) < pb.M;
-    const bool w_n0 = (N0 + wn * 32) < pb.N, w_n1 = (N0 + wn * 32 + 16) < pb.N;
+    const bool w_m0 = (M0 + wr0) < pb.M, w_m1 = !narrow && (M0 + wr0 + 16) < pb.M;
+    const bool w_n0 = (N0 + wc0) < pb.N, w_n1 = (N0 + wc0 + 16) < pb.N;
     auto compute = [&](int cur) {
         if (w_m0 && w_n0) {
             const d4 a0 = *(const d4*)(&sA[cur][arow0]);
@@ -454,9 +457,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
         }
     }
     // ---- epilogue (as k_gemm_nt): accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
-    const int m0 = M0 + wm * 32, n0 = N0 + wn * 32;
+    const int m0 = M0 + wr0, n0 = N0 + wc0;
     if (m0 >= pb.M || n0 >= pb.N) return;
-    const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
+    const bool mv1 = !narrow && (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
     int bc0 = n0 + r, bc1 = n0 + 16 + r;
     if (pb.idxB) { bc0 = gldi(pb.idxB + n0 + r); bc1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1; }
     // COV / HOSTCOV: everything the epilogue reads per row and per column (gather indices, coordinates,
