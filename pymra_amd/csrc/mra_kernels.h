@@ -522,18 +522,19 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
 //  16x16 diagonal block: Cholesky + inverse of the factor, one row per lane (lanes 0..15)
 // ------------------------------------------------------------------------------------------------
 // a[k] = T[lane][k] (k <= lane valid, 0 above the diagonal).  On return a[k] = L[lane][k] (0 above the
-// diagonal), mr[k] = (L^{-1})[lane][k] (row `lane` of the inverse, 0 above the diagonal).  Returns sum(log diag L) and sets
-// bad when a pivot is not positive.  All 64 lanes call it with lane = (lane id & 15) (the four 16-lane
-// groups do the same work); sc = 272 doubles of LDS scratch private to the wave.
+// diagonal), mr[k] = (L^{-1})[lane][k] (row `lane` of the inverse, 0 above the diagonal).  Returns
+// sum(log diag L) and sets bad when a pivot is not positive.  All 64 lanes call it with
+// lane = (lane id & 15): the four rows of 16 lanes do the same work.
 //
 // This serial 16x16 step is the latency floor of every small factorisation on the path (knot pass,
-// fronts, the leaves' C blocks), so it is written for a short dependent chain rather than for
-// throughput: right-looking with one row per lane; per column the un-normalised entries c_i = A[i][j]
-// go through LDS once (one ds_write_b64, broadcast ds_reads) and every lane applies
-// A[i][k] -= (c_i / d_j) c_k with its own Newton reciprocal of the pivot d_j = c_j.  Square roots
-// (v_rsq_f64 + Goldschmidt, no division) are off the critical path: L[i][j] = c_i * rsqrt(d_j).
-// The inverse comes from applying the same row operations to the identity (row j of the unit-lower
-// inverse is final at step j and rides the same LDS exchange), scaled by rsqrt(d_i) at the end.
+// fronts, the leaves' C blocks: 3.3 us per call), so it is written for a short dependent chain:
+// right-looking with one row per lane; per column every lane fetches the un-normalised entries
+// c_k = A[k][j] from their owner lanes with DPP row broadcasts (VALU moves: no LDS round trip, no
+// v_readlane scalar hazards) and applies A[i][k] -= (c_i / d_j) c_k with its own Newton reciprocal of
+// the pivot d_j = c_j.  Square roots (v_rsq_f64 + Goldschmidt, no division) are off the critical
+// path: L[i][j] = c_i * rsqrt(d_j).  The inverse comes from applying the same row operations to the
+// identity (row j of the unit-lower inverse is final at step j), scaled by rsqrt(d_i) at the end.
+// What is left on the chain is sixteen dependent reciprocals.
 __device__ __forceinline__ void lds_wave_sync() {
     // LDS operations of one wave complete in program order; this only stops the compiler from moving
     // or forwarding memory accesses across the exchange
@@ -561,28 +562,47 @@ __device__ __forceinline__ double rsqrt_pos(double d) {          // 1/sqrt(d), d
     h = __builtin_fma(h, e, h);
     return h + h;
 }
-__device__ __forceinline__ double chol16_inv(double a[16], double mr[16], int lane, bool& bad, double* __restrict__ sc) {
+// value of lane k of the caller's row of 16 lanes (DPP row_newbcast: one VALU move per 32 bits, no LDS round trip and
+// no scalar-register hazard); k is a constant after unrolling, the switch folds to one instruction
+__device__ __forceinline__ int row_bcast_i(int v, int k) {
+    switch (k) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 0, 0xf, 0xf, false);
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 1, 0xf, 0xf, false);
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 2, 0xf, 0xf, false);
+        case 3: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 3, 0xf, 0xf, false);
+        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 4, 0xf, 0xf, false);
+        case 5: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 5, 0xf, 0xf, false);
+        case 6: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 6, 0xf, 0xf, false);
+        case 7: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 7, 0xf, 0xf, false);
+        case 8: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 8, 0xf, 0xf, false);
+        case 9: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 9, 0xf, 0xf, false);
+        case 10: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 10, 0xf, 0xf, false);
+        case 11: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 11, 0xf, 0xf, false);
+        case 12: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 12, 0xf, 0xf, false);
+        case 13: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 13, 0xf, 0xf, false);
+        case 14: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 14, 0xf, 0xf, false);
+        case 15: return __builtin_amdgcn_update_dpp(0, v, 0x150 + 15, 0xf, 0xf, false);
+    }
+    return v;
+}
+__device__ __forceinline__ double row_bcast(double x, int k) {
+    return __hiloint2double(row_bcast_i(__double2hiint(x), k), row_bcast_i(__double2loint(x), k));
+}
+__device__ __forceinline__ double chol16_inv(double a[16], double mr[16], int lane, bool& bad, double* __restrict__ /*sc: unused*/) {
     // opaque copy of the lane number: keeps the per-lane masks / unit vectors below from being hoisted
     // out of the caller's tile loop (dozens of live registers across the whole factorisation)
     asm volatile("" : "+v"(lane));
-    double* col = sc + 256;
     double dsel = 1.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) mr[k] = (k == lane) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        col[lane] = a[j];
-        if (lane == j) {                 // row j of the unit-lower inverse is final: share it
-#pragma unroll
-            for (int k = 0; k <= j; k += 2) *(double2*)(sc + j * 16 + k) = double2{mr[k], mr[k + 1]};
-        }
-        lds_wave_sync();
+        // column j of the trailing matrix (entry k comes from lane k) and row j of the unit-lower inverse (from lane j)
         double c[16], mj[16];
 #pragma unroll
-        for (int k = j; k < 16; ++k) c[k] = col[k];
+        for (int k = j; k < 16; ++k) c[k] = row_bcast(a[j], k);
 #pragma unroll
-        for (int k = 0; k <= j; ++k) mj[k] = sc[j * 16 + k];
-        lds_wave_sync();
+        for (int k = 0; k <= j; ++k) mj[k] = row_bcast(mr[k], j);
         double d = c[j];
         if (!(d > 0.0)) { bad = true; d = 1.0; }
         const double t = (lane > j) ? a[j] * rcp_pos(d) : 0.0;
