@@ -783,7 +783,7 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
 }
 
 template <int NTMAX>
-__global__ __launch_bounds__(256) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
+__global__ __launch_bounds__(256, 3) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
                                                     double* __restrict__ dnode, int* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16 + 32];     // 272 used: tile + exchange column
     __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
