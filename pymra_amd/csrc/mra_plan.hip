@@ -1114,9 +1114,10 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         if (!pl->direct_parent) ensure_gt(pl);
         if (!pl->direct_parent) { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk); launch_gemm<EPI_SET>(pl, pl->gLeafSyrk.p, nl, pl->leaf_max_na, pl->leaf_max_na, false, true); }
         if (pred) {
-            // fork: everything below only feeds the predictive pass.  With per-kernel timing on it stays on the main
+            // fork: everything below only feeds the predictive pass.  In a sharded run it goes to the side stream, so that
+            // the front chain and the all-reduce do not queue behind it; with per-kernel timing on it stays on the main
             // stream so that the hipEvent brackets measure one kernel at a time.
-            const bool side = !pl->ktiming;
+            const bool side = !pl->ktiming && pl->reduce_level >= 0;   // sharded runs only: on one GPU it buys nothing
             hipStream_t main_stream = pl->stream;
             if (side) {
                 HIP_TRY(hipEventRecord(pl->ev_fork, main_stream));

@@ -17,15 +17,33 @@ if ks:
 def family(name, grid, maxgrid):
     """rocprof kernel name (+ grid) -> bench.py kernel family name"""
     if name.startswith("void k_prior_cascade"):
-        return "k_trsm_rows prior / fused prior cascade" if grid == maxgrid.get("cascade") else "k_gemm_nt<COV> prior resid"
+        return "k_trsm_rows prior / fused prior cascade" if grid == maxgrid.get("cascade") else "k_panel_chol prior / fused knot pass"
     if name.startswith("void k_predict_cascade"): return "k_gemm_nt<SUB> predict update / fused predict cascade"
     if name.startswith("void k_gemm_nt_lds<2"): return "k_gemm_nt<COV> leaf resid" if grid == maxgrid.get("cov") else "small kernels"
     if name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt<SUB> leaf update"
     if name.startswith("void k_gemm_nt<0"): return "k_gemm_nt<SET> leaf syrk"
     if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front schur"
     if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_panel_chol leaf"
-    if name.startswith("k_panel_chol"): return "k_panel_chol prior+front"
+    if name.startswith("k_panel_chol"): return "k_panel_chol front"
     return "small kernels"
+
+# per-family launch durations from the kernel trace of the --stats run (the stats CSV aggregates by kernel NAME, and one
+# name can serve two families: k_prior_cascade is both the knot pass and the row cascade): these are the averages to
+# set beside bench.py's roofline.avg_launch_ms
+kt = one("kt/*/*_kernel_trace.csv")
+if kt:
+    rows = list(csv.DictReader(open(kt)))
+    gs = lambda r: int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))
+    mg = {}
+    for r in rows:
+        n, g = r["Kernel_Name"], gs(r)
+        if n.startswith("void k_prior_cascade"): mg["cascade"] = max(mg.get("cascade", 0), g)
+        if n.startswith("void k_gemm_nt_lds<2"): mg["cov"] = max(mg.get("cov", 0), g)
+    fam_d = collections.defaultdict(list)
+    for r in rows:
+        fam_d[family(r["Kernel_Name"], gs(r), mg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    json.dump({f: {"launches": len(v), "avg_us": sum(v) / len(v), "total_us": sum(v)} for f, v in sorted(fam_d.items())},
+              open(os.path.join(dst, tag + "_kernel_family_durations.json"), "w"), indent=1)
 
 summary = {}
 for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
