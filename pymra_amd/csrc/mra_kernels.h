@@ -1031,6 +1031,7 @@ struct CascadeArgs {
     double* Lp_out;           // [node][cw][cw]
     double* invd_out;         // [node][cwt][256]
     int* err;
+    int node_base;            // KNOT: node number of slot 0 of the level being factorised (error reports name node + 1)
 };
 
 // tiles staged for level m: Wk [jb][k*CWT+kt] (CWT*m*CWT), strictly-lower L (NTRI), inverted diagonals (CWT)
@@ -1307,7 +1308,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             double* s_si = s_sd + 288;
             bool bad = false;
             chol_wave_body(ar.Lp_out + (long)slotk * CW * CW, CW, CWT, ar.invd_out + (long)slotk * CWT * 256, s_sd, s_si, lane, bad);
-            if (bad && lane == 0) atomicMax(ar.err, 1000000 + slotk);
+            if (bad && lane == 0) atomicMax(ar.err, ar.node_base + slotk + 1);
         }
     }
 }

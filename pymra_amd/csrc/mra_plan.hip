@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <rccl/rccl.h>      // types and enum values only: the library itself is loaded with dlopen at run time
 #include <string>
 #include <vector>
 
@@ -208,8 +209,10 @@ struct mra_plan {
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> kev;
     // comm
     void* rccl = nullptr;
-    void* comm = nullptr;
+    ncclComm_t comm = nullptr;
+    ncclResult_t (*allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     int n_ranks = 1, rank = 0;
+    bool pass_open = false;              // a pass was started and has not reached finish_run (error or abandoned split)
 };
 
 static int fail(mra_plan* p, const MraError& e) {
@@ -811,6 +814,7 @@ static void run_prior_fused(mra_plan* pl) {
         ar.tile_rows = pl->fl[m].kt_rows.p; ar.tile_chain = pl->fl[m].kt_chain.p; ar.tile_knot0 = pl->fl[m].kt_knot0.p;
         ar.Wk_out = pl->fl[m].Wk.p;
         ar.Lp_out = lv.Lp.p; ar.invd_out = lv.invP.p; ar.err = pl->errflag.p;
+        ar.node_base = (int)pl->level_ptr[m];            // regular trees: slot s of level m is node level_ptr[m] + s
         launch_cascade_any(pl, ar);
     }
     {
@@ -921,13 +925,12 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                                        lv.F.p + (lv.F.n - 16));
                 }
                 if (pl->run_flags & MRA_RUN_SPLIT) { pl->split_pending = true; return; }
-                if (pl->comm) {
-                    typedef int (*allreduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-                    allreduce_t fn = (allreduce_t)dlsym(pl->rccl, "ncclAllReduce");
-                    if (!fn) throw MraError(MRA_ERR_COMM, "ncclAllReduce not found");
-                    const int rc = fn(lv.F.p, lv.F.p, lv.F.n, /*ncclDouble*/ 8, /*ncclSum*/ 0, pl->comm, pl->stream);
-                    if (rc != 0) throw MraError(MRA_ERR_COMM, "ncclAllReduce failed");
-                }
+                // a reduce level without a transport would silently build the likelihood from this rank's partial fronts
+                if (!pl->comm || !pl->allreduce)
+                    throw MraError(MRA_ERR_STATE, "reduce level set but neither a communicator (mra_comm_init) nor MRA_RUN_SPLIT: "
+                                                  "the fronts of the reduce level would not be summed over ranks");
+                if (pl->allreduce(lv.F.p, lv.F.p, lv.F.n, ncclDouble, ncclSum, pl->comm, pl->stream) != ncclSuccess)
+                    throw MraError(MRA_ERR_COMM, "ncclAllReduce failed");
             }
         }
         if (is_red) run_add_identity(pl, m);
@@ -1008,6 +1011,7 @@ static void finish_run(mra_plan* pl) {
     pl->kev.clear();
     pl->ran = true;
     pl->split_pending = false;
+    pl->pass_open = false;
     if (errv) {
         char b[160];
         snprintf(b, sizeof b, "matrix not positive definite in node %d (Cholesky pivot <= 0 or NaN)", errv - 1);
@@ -1030,6 +1034,20 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     if (!(pl->have_locs && pl->have_obs && pl->have_kernel))
         throw MraError(MRA_ERR_STATE, "mra_run needs set_locs, set_obs and set_kernel first");
     HIP_TRY(hipSetDevice(pl->device));
+    if (pl->pass_open) {
+        // the previous pass never reached finish_run (an error was thrown, or a split run was abandoned before
+        // mra_run_resume): wait for whatever it left on the two streams, and clear the device error flag that
+        // only the last kernel of a pass resets
+        if (pl->side_pending) HIP_TRY(hipStreamWaitEvent(pl->stream, pl->ev_join, 0));
+        HIP_TRY(hipStreamSynchronize(pl->stream));
+        HIP_TRY(hipStreamSynchronize(pl->stream2));
+        HIP_TRY(hipMemsetAsync(pl->errflag.p, 0, sizeof(int), pl->stream));
+        for (auto& e : pl->kev) { hipEventDestroy(e.second.first); hipEventDestroy(e.second.second); }
+        pl->kev.clear();
+    }
+    pl->side_pending = false;
+    pl->split_pending = false;
+    pl->pass_open = true;
     pl->run_flags = flags;
     for (int k = 0; k < KF_COUNT; ++k) pl->kstat[k] = mra_plan::KStat();
     const bool pred = flags & MRA_RUN_PREDICT;
@@ -1119,6 +1137,10 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             // stream so that the hipEvent brackets measure one kernel at a time.
             const bool side = !pl->ktiming && pl->reduce_level >= 0;   // sharded runs only: on one GPU it buys nothing
             hipStream_t main_stream = pl->stream;
+            struct StreamGuard {                                   // a throw below must not leave later launches on the side stream
+                mra_plan* p; hipStream_t s;
+                ~StreamGuard() { p->stream = s; }
+            } guard{pl, main_stream};
             if (side) {
                 HIP_TRY(hipEventRecord(pl->ev_fork, main_stream));
                 HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->ev_fork, 0));
@@ -1225,7 +1247,7 @@ int mra_plan_destroy(mra_plan* pl) {
     if (!pl) return MRA_OK;
     hipSetDevice(pl->device);
     if (pl->comm && pl->rccl) {
-        typedef int (*destroy_t)(void*);
+        typedef ncclResult_t (*destroy_t)(ncclComm_t);
         destroy_t fn = (destroy_t)dlsym(pl->rccl, "ncclCommDestroy");
         if (fn) fn(pl->comm);
     }
@@ -1273,6 +1295,20 @@ int mra_plan_set_obs(mra_plan* pl, const double* y, double R) {
         HIP_TRY(hipSetDevice(pl->device));
         HIP_TRY(hipMemcpy(pl->y.p, y, (size_t)pl->P * sizeof(double), hipMemcpyHostToDevice));
         pl->R = R;
+        if (pl->host_cov) {
+            // host-evaluated covariance blocks are per observed row: a new observation pattern invalidates them (and
+            // build_leaf rebuilds the leaf descriptors without their Csrc pointers).  The caller has to select
+            // MRA_KERNEL_HOST and upload the blocks again; until then mra_run reports MRA_ERR_STATE.
+            pl->host_cov = false;
+            pl->have_kernel = false;
+            pl->covsrc.release();
+            pl->covdiag.release();
+            for (auto& lv : pl->lev)
+                if (!lv.nodes.empty()) {
+                    for (auto& g : lv.hResid) { g.Csrc = nullptr; g.ldcs = 0; }
+                    lv.gResid.upload(lv.hResid);
+                }
+        }
         build_leaf(pl, y);
         pl->have_obs = true;
         return MRA_OK;
@@ -1540,9 +1576,9 @@ int mra_comm_unique_id(char* out, int cap) {
     void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) { g_last_error = "cannot load librccl.so"; return MRA_ERR_COMM; }
-    typedef int (*uid_t_)(void*);
+    typedef ncclResult_t (*uid_t_)(ncclUniqueId*);
     uid_t_ fn = (uid_t_)dlsym(h, "ncclGetUniqueId");
-    if (!fn || fn(out) != 0) { g_last_error = "ncclGetUniqueId failed"; return MRA_ERR_COMM; }
+    if (!fn || fn((ncclUniqueId*)out) != ncclSuccess) { g_last_error = "ncclGetUniqueId failed"; return MRA_ERR_COMM; }
     return MRA_OK;
 }
 
@@ -1553,12 +1589,15 @@ int mra_comm_init(mra_plan* pl, const char* uid, int n_ranks, int rank) {
         pl->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!pl->rccl) pl->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!pl->rccl) throw MraError(MRA_ERR_COMM, "cannot load librccl.so");
-        struct Uid { char b[128]; } id;
-        memcpy(id.b, uid, 128);
-        typedef int (*init_t)(void**, int, Uid, int);
+        ncclUniqueId id;
+        static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+        memcpy(&id, uid, sizeof id);
+        typedef ncclResult_t (*init_t)(ncclComm_t*, int, ncclUniqueId, int);
         init_t fn = (init_t)dlsym(pl->rccl, "ncclCommInitRank");
         if (!fn) throw MraError(MRA_ERR_COMM, "ncclCommInitRank not found");
-        if (fn(&pl->comm, n_ranks, id, rank) != 0) throw MraError(MRA_ERR_COMM, "ncclCommInitRank failed");
+        pl->allreduce = (decltype(pl->allreduce))dlsym(pl->rccl, "ncclAllReduce");
+        if (!pl->allreduce) throw MraError(MRA_ERR_COMM, "ncclAllReduce not found");
+        if (fn(&pl->comm, n_ranks, id, rank) != ncclSuccess) { pl->comm = nullptr; throw MraError(MRA_ERR_COMM, "ncclCommInitRank failed"); }
         pl->n_ranks = n_ranks; pl->rank = rank;
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }

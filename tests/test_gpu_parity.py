@@ -150,6 +150,66 @@ def test_sharded_on_one_gpu_equals_single(hip):
     assert np.max(np.abs(m - mean)) < 1e-12 and np.max(np.abs(v - var)) < 1e-13
 
 
+@pytest.mark.parametrize("case,world", [("c2", 4), ("c2", 8), ("g64m", 8), ("g64", 5)])
+def test_sharded_4_and_8_ways_on_one_gpu(hip, case, world):
+    """BASELINE config 4's layouts (4 GPUs: shard level 1; 8 GPUs: shard level 2 with orphan knot rows of two
+    upper levels and reduce level 1) through the HIP path: all ranks emulated on one GPU with the split /
+    export / import entry points, against the single-plan HIP result and the oracle."""
+    from oracle.mra_levelwise import run_levelwise
+    cs = K.load_case(case)
+    pl, lik, mean, var = run_hip(hip, cs)
+    pl.close()
+    liks, m, v, s = K.emulate_world_on_one_gpu(hip, cs["topo"], cs["locs"], cs["y_obs"], cs["c"]["R"], cs["spec"], world)
+    assert s == (1 if world <= 4 else 2)
+    assert max(abs(l - lik) for l in liks) <= 1e-12 * abs(lik)
+    assert np.max(np.abs(m - mean)) < 1e-11 and np.max(np.abs(v - var)) < 1e-12
+    if case != "c2":
+        ref = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+        assert abs(liks[0] - ref["lik"]) <= 1e-11 * abs(ref["lik"]) and np.max(np.abs(m - ref["mean"])) < 1e-10
+
+
+def test_state_errors_are_status_codes_not_faults(hip):
+    """(1) new observations on a plan that uses host-evaluated covariance blocks invalidate the blocks: mra_run must
+    return MRA_ERR_STATE until they are uploaded again (it used to launch with a null block pointer);
+    (2) a reduce level without communicator and without MRA_RUN_SPLIT must not silently skip the exchange;
+    (3) a plan is usable again after an abandoned split run and after an error."""
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("g32")
+    cov = lambda a, b: np.asarray(mt.ExpCovFun(a, b, l=cs["c"]["l"]))
+    pl = hip.HipPlan(cs["topo"], 0)
+    pl.set_locs(cs["locs"]); pl.set_obs(cs["y_obs"], cs["c"]["R"])
+    pl.upload_host_cov(cov, cs["locs"], cs["y_obs"])
+    pl.run(True, True)
+    lik0 = sum(pl.likelihood())
+    y2 = cs["y_obs"].copy()
+    y2[np.nonzero(np.isfinite(y2.ravel()))[0][:7]] = np.nan
+    pl.set_obs(y2, cs["c"]["R"])
+    with pytest.raises(hip.MraError) as e:
+        pl.run(True, True)
+    assert e.value.code == -4
+    pl.upload_host_cov(cov, cs["locs"], y2)
+    pl.run(True, True)
+    assert sum(pl.likelihood()) != lik0
+    pl.close()
+    # (2) + (3)
+    from pymra_amd.sharding import shard_topology
+    lt, red = shard_topology(cs["topo"], 2, 0)
+    p = hip.HipPlan(lt, 0)
+    p.set_locs(cs["locs"]); p.set_obs(cs["y_obs"], cs["c"]["R"]); p.set_kernel(cs["spec"].kind, cs["spec"].l, cs["spec"].sig, 1.0)
+    p.set_reduce_level(red)
+    with pytest.raises(hip.MraError) as e:
+        p.run(True, True)
+    assert e.value.code == -4
+    p.run(True, True, split=True)                   # abandoned: never resumed
+    p.run(True, True, split=True)
+    b1 = p.reduce_export()
+    p.reduce_import(b1); p.resume()
+    l1 = sum(p.likelihood())
+    p.run(True, True, split=True); p.reduce_import(p.reduce_export()); p.resume()
+    assert sum(p.likelihood()) == l1
+    p.close()
+
+
 def test_other_device_kernels_against_oracle(hip):
     """Matern52 / Gaussian / scaled kernels (pyMRA/MRATools.py:281-301) on the device."""
     import pymra_amd.MRATools as mt

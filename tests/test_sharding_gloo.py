@@ -33,7 +33,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("case,world", [("g32", 2), ("g64", 2), ("c1", 3)])
+@pytest.mark.parametrize("case,world", [("g32", 2), ("g64", 2), ("c1", 3), ("g64", 8)])
 def test_sharded_equals_single(tmp_path, case, world):
     from oracle.mra_levelwise import run_levelwise
     cs = K.load_case(case)
@@ -48,6 +48,8 @@ def test_sharded_equals_single(tmp_path, case, world):
     subprocess.run(cmd, env=env, check=True, timeout=600, capture_output=True)
     r = np.load(out)
     assert int(r["red"]) >= 0 and int(r["P_local"]) < cs["topo"].P
+    if world == 8:
+        assert int(r["red"]) == 1          # the 8-GPU layout of BASELINE config 4: shard level 2, orphan knot rows of two upper levels
     assert abs(float(r["lik"]) - full["lik"]) <= 1e-12 * abs(full["lik"])
     assert np.max(np.abs(r["mean"] - full["mean"])) < 1e-12
     assert np.max(np.abs(r["var"] - full["var"])) < 1e-12
@@ -71,3 +73,17 @@ def test_shard_bookkeeping():
             assert np.all((kq >= lt.node_row0[i]) & (kq < lt.node_row1[i]))
             assert np.array_equal(np.sort(lt.perm[kq]), np.sort(t.perm[t.knot_rows[t.knot_ptr[0]:t.knot_ptr[1]]])) or i > 0
     assert np.all(seen == 1)                                # every caller row is owned by exactly one rank
+
+
+@pytest.mark.parametrize("case,world,s_expected", [("g64", 4, 1), ("g64", 5, 2), ("g64", 8, 2), ("g64m", 8, 2), ("g128m", 8, 2)])
+def test_shard_levels_1_and_2_through_the_oracle(case, world, s_expected):
+    """Every rank of a 4/5/8-way sharded run (shard level 1 and 2: what BASELINE config 4 uses at 4 and 8 GPUs),
+    emulated in-process with the level-wise oracle: identical likelihood on every rank, means and variances
+    assembled from the ranks' own rows equal the single-plan result."""
+    from oracle.mra_levelwise import run_levelwise
+    cs = K.load_case(case)
+    full = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+    liks, mean, var, s = K.emulate_world_oracle(cs["topo"], cs["locs"], cs["y_obs"], cs["c"]["R"], cs["spec"], world)
+    assert s == s_expected
+    assert max(abs(l - full["lik"]) for l in liks) <= 1e-13 * abs(full["lik"])
+    assert np.max(np.abs(mean - full["mean"])) < 1e-12 and np.max(np.abs(var - full["var"])) < 1e-13
