@@ -127,6 +127,27 @@ int mra_get_predict(mra_plan *plan, double *mean_perm, double *var_perm);
  * copies min(capacity, available) doubles into out, returns the available count in *n_avail. */
 int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int64_t *n_avail);
 
+/* Replaces: the per-node attributes the reference leaves on its Node objects - B, kInv (pyMRA/MRANode.py:384-385),
+ * kTil, A, omg (:426-445), BTil (:486-495) - which its diagnostics read (MRATree.getBasisFunctionsMatrix,
+ * pyMRA/MRATree.py:445-511; pyMRA/tests/debug-posterior.py:97-109).  The device keeps them in whitened form
+ * (DESIGN.md section 3); this call copies one node's raw block, pymra_amd.diagnostics de-whitens on the host:
+ *   MRA_BLOCK_W_ROWS  the node's rows of the whitened basis array W, all ldw columns (N_j x ldw).  After a
+ *                     likelihood-only run: the prior W (B_k[S_j] = W[:, block k] L_k^T).  After a predict run with
+ *                     MRA_OPT_FUSED off: block m of a level-m non-leaf node's rows holds X = BTil_j[m] (L_j Lt_j)^-T
+ *                     (X X^T = BTil[m] kTil BTil[m]^T), the blocks of coarser levels hold the rows of BTil[k] L_k^-T
+ *                     as the node's parent sees them.
+ *   MRA_BLOCK_LPRIOR  non-leaf: L_j, cw x cw lower Cholesky factor of kInv_j (padded with the identity)
+ *   MRA_BLOCK_FRONT   non-leaf: the factorised front, nf x nf (lower triangle): Lt_j (cw x cw), Zt_j below it
+ *                     (na x cw), the Schur block Gt_j (na x na) - whitened ATil / omgTil / u (last block = y)
+ *   MRA_BLOCK_LEAF    leaf: the panel [C = v_m(o,o) + R I -> Lc ; Ut ; Tt], (nop + na + N_j) x nop
+ * out receives min(capacity, rows*cols) doubles row-major; *n_rows, *n_cols the block shape. */
+#define MRA_BLOCK_W_ROWS   0
+#define MRA_BLOCK_LPRIOR   1
+#define MRA_BLOCK_FRONT    2
+#define MRA_BLOCK_LEAF     3
+int mra_get_node_block(mra_plan *plan, int32_t node, int what, double *out, int64_t capacity,
+                       int64_t *n_rows, int64_t *n_cols);
+
 /* Per-phase device milliseconds of the last mra_run (hipEvent deltas on the plan's stream):
  * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written.
  * The four phase entries are measured only while MRA_OPT_KERNEL_TIMING is on (0 otherwise): an event

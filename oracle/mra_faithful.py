@@ -76,6 +76,7 @@ class _Recursion:
         self.pruned = pruned or {}
         self.tm = dict(prior=0.0, posterior=0.0, gc=0.0)
         self.count = 0
+        self.keep = None                      # dict: finished nodes are parked here instead of being deleted (tests)
 
     # -- topology helpers ----------------------------------------------------------------
     def rows(self, i):
@@ -178,7 +179,10 @@ class _Recursion:
             s.var[sel] += st[c].var
         self.tm["posterior"] += time.perf_counter() - t0
         for c in kids:                       # the reference pops and deletes the children here
-            del st[c]
+            if self.keep is None:
+                del st[c]
+            else:
+                self.keep[c] = st.pop(c)
         if self.do_gc:
             t1 = time.perf_counter()
             gc.collect()
@@ -192,13 +196,19 @@ class _Recursion:
         self.count += 1
 
 
-def run_faithful(topo, locs, cov, obs, R: float, *, do_gc: bool = False, timers: Optional[dict] = None):
-    """Evaluate the whole tree.  Returns dict(lik, d, u, mean[N], var[N], sd[N])."""
+def run_faithful(topo, locs, cov, obs, R: float, *, do_gc: bool = False, timers: Optional[dict] = None,
+                 keep_nodes: Optional[dict] = None):
+    """Evaluate the whole tree.  Returns dict(lik, d, u, mean[N], var[N], sd[N]).  ``keep_nodes``: a dict that
+    receives every node's finished state (B, kInv, K, kC, A, omg, kTil, BTil, d, u, mean, var; rows in padded
+    leaf order) keyed by node number, for the per-node golden blocks."""
     sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
     rec = _Recursion(topo, locs, cov, obs, R, do_gc)
+    rec.keep = keep_nodes
     root = 0
     rec.visit(root)
     s = rec.st[root]
+    if keep_nodes is not None:
+        keep_nodes[root] = s
     mean = np.zeros(topo.N)
     var = np.zeros(topo.N)
     real = topo.perm >= 0

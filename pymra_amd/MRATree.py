@@ -106,6 +106,7 @@ class MRATree(object):
             raise TypeError("R must be a Python float (scalar nugget variance); got %r" % type(R))
         obs_arr = np.asarray(obs, dtype=np.float64)
         self.obs_inds = np.where(np.logical_not(np.isnan(obs_arr)))[0]
+        self.obs, self.R = obs_arr, R
 
         spec = probe_cov(cov, self.d, np.asarray(locs, dtype=np.float64))
         if spec is not None and spec.circular and self.d != 1:
@@ -142,6 +143,27 @@ class MRATree(object):
         xP = self.root.mean
         sdP = np.sqrt(self.root.var)
         return xP, sdP
+
+    # ---- diagnostics surface (pyMRA/MRATree.py:101-132, 445-511); host-side de-whitening, see pymra_amd.diagnostics
+    def getNodeBlocks(self, posterior=True):
+        """Per-node ``B, kInv, k, kC`` (+ ``A, omg, kTil, kTilC, BTil[res]``, cumulative ``d, u``) of every node
+        in level order - the attributes the reference keeps on its ``Node`` objects (pyMRA/MRANode.py:384-391,
+        415-445, 486-507).  Costs two device passes."""
+        from .diagnostics import collect_node_blocks
+        return collect_node_blocks(self, posterior=posterior)
+
+    def getNodesBFS(self, groupByResolution=False):
+        """Nodes in breadth-first order (pyMRA/MRATree.py:101-120) as ``NodeBlocks`` records.  (In the reference
+        the tree is torn down at the end of construction, MRANode.py:108-111, and only the root is ever seen.)"""
+        nodes = self.getNodeBlocks(posterior=True)
+        if not groupByResolution:
+            return nodes
+        return [[nb for nb in nodes if nb.res == m] for m in range(self.topology.n_levels)]
+
+    def getBasisFunctionsMatrix(self, distr="prior", groupByResolution=False, order='root', timesKC=False):
+        """pyMRA/MRATree.py:445-511."""
+        from .diagnostics import basis_functions_matrix
+        return basis_functions_matrix(self, distr, groupByResolution, order, timesKC)
 
     # re-evaluate with other kernel parameters on the same tree (plan reuse for MLE loops,
     # README.md:96-104 builds a new MRATree per objective call)

@@ -2,5 +2,6 @@
 behind pyMRA's own Python surface (MRATree / MRATools).  See DESIGN.md."""
 from . import MRATools            # noqa: F401
 from .MRATree import MRATree      # noqa: F401
+from . import DataLoader           # noqa: F401
 
-__all__ = ["MRATree", "MRATools"]
+__all__ = ["MRATree", "MRATools", "DataLoader"]

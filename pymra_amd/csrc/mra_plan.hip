@@ -1441,6 +1441,39 @@ int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_
     } catch (const MraError& e) { return fail(pl, e); }
 }
 
+int mra_get_node_block(mra_plan* pl, int32_t node, int what, double* out, int64_t cap, int64_t* n_rows, int64_t* n_cols) {
+    if (!pl || !n_rows || !n_cols) return MRA_ERR_INVALID;
+    try {
+        if (node < 0 || node >= pl->n_nodes) throw MraError(MRA_ERR_INVALID, "node out of range");
+        if (!pl->ran) throw MraError(MRA_ERR_STATE, "mra_run has not completed");
+        HIP_TRY(hipSetDevice(pl->device));
+        const int m = pl->node_level[node];
+        const double* src = nullptr;
+        int64_t rows = 0, cols = 0, ld = 0;
+        if (what == MRA_BLOCK_W_ROWS) {
+            rows = pl->row1[node] - pl->row0[node]; cols = pl->ldw; ld = pl->ldw;
+            src = pl->W.p + pl->row0[node] * (long)pl->ldw;
+        } else if (what == MRA_BLOCK_LPRIOR || what == MRA_BLOCK_FRONT) {
+            if (pl->leaf[node]) throw MraError(MRA_ERR_INVALID, "block exists for non-leaf nodes only");
+            const LevelData& lv = pl->lev[m];
+            const size_t sl = (size_t)pl->node_slot[node];
+            if (what == MRA_BLOCK_LPRIOR) { rows = cols = ld = lv.cw; src = lv.Lp.p + sl * (size_t)lv.cw * lv.cw; }
+            else { rows = cols = ld = lv.nf; src = lv.F.p + sl * (size_t)lv.nf * lv.nf; }
+        } else if (what == MRA_BLOCK_LEAF) {
+            if (!pl->leaf[node]) throw MraError(MRA_ERR_INVALID, "block exists for leaves only");
+            const int t = pl->leaf_slot[node];
+            const int nop = pl->leaf_nop[t];
+            rows = nop + pl->na[m] + (pl->row1[node] - pl->row0[node]); cols = ld = nop;
+            src = pl->panel.p + pl->leaf_poff[t];
+        } else throw MraError(MRA_ERR_INVALID, "unknown block id");
+        *n_rows = rows; *n_cols = cols;
+        const int64_t n = std::min<int64_t>(cap, rows * cols);
+        if (out && n > 0) HIP_TRY(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        (void)ld;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
 int mra_get_timers(mra_plan* pl, double* out, int cap) {
     if (!pl || !out) return 0;
     int n = std::min(cap, 5);

@@ -1,0 +1,236 @@
+"""Per-node blocks and the basis-function matrix, de-whitened on the host from the device's buffers.
+
+The reference leaves ``B, kInv, k, kC`` (pyMRA/MRANode.py:384-391), ``A, omg, kTil`` (:415-445) and
+``BTil`` (:486-495) as attributes on every ``Node`` and reads them in its diagnostics
+(``MRATree.getBasisFunctionsMatrix``, pyMRA/MRATree.py:445-511; pyMRA/tests/debug-posterior.py:97-109).
+The GPU path never forms them: it works with the whitened basis ``W^m = B_m L_m^{-T}`` (``L_m L_m^T = kInv``)
+and with fronts that hold ``Lt`` (``Lt Lt^T = I + L^{-1} A_mm L^{-T}``), ``Zt`` and the Schur block.  This
+module fetches those raw blocks through ``mra_get_node_block`` and turns them back into the reference's
+quantities with small dense host operations (diagnostics are O(N r) per node; they are meant for the same
+small problems the reference's diagnostics are usable on):
+
+    B_j          = W^m[S_j] L_j^T                      kInv_j = L_j L_j^T        k_j = kInv_j^{-1}
+    A_j[k][l]    = L_k G_kl L_l^T,  omg_j[k] = L_k g_k  with G = whitened front before elimination
+                   (G_mm = Lt Lt^T - I, G_am = Zt Lt^T, G_aa = Gt + Zt Zt^T)
+    kTil_j       = ((L_j Lt_j)(L_j Lt_j)^T)^{-1}
+    BTil_j[m]    = X (L_j Lt_j)^T   with X = W~^m[S_j] Lt_j^{-T} (what the level-by-level predictive pass leaves in W)
+
+Leaves of the reference are ordinary nodes whose knots are all of their not-yet-used locations
+(MRANode.py:42-45); the device treats them in observation space instead, so their blocks are rebuilt here
+from the prior basis of their ancestors: ``B_leaf = C(S,Q) - sum_k W^k[S] W^k[Q]^T``.
+
+Two device passes are made: likelihood-only (W = prior basis) and a full pass with the level-by-level
+kernels (``MRA_OPT_FUSED`` off; the fused predictive cascade keeps the per-level tiles in registers and never
+writes them back).  Product code: no oracle involved.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import scipy.linalg as sla
+
+from . import plan as P
+
+YB = 16
+
+
+class NodeBlocks:
+    """What the reference keeps on a ``Node`` (names as in pyMRA/MRANode.py).  ``rows`` are the caller's row
+    indices of the node's locations in ascending order (the order of ``Node.locs``)."""
+    __slots__ = ("ID", "res", "index", "leaf", "rows", "kInds", "N", "B", "kInv", "k", "kC",
+                 "A", "omg", "kTil", "kTilC", "BTil", "d", "u")
+
+    def __repr__(self):
+        return "NodeBlocks(%s, res=%d, N=%d, rank=%d%s)" % (self.ID, self.res, self.N, len(self.kInds), ", leaf" if self.leaf else "")
+
+
+def _layout(topo):
+    cw = np.asarray(topo.cw, dtype=np.int64)
+    L = topo.n_levels
+    coff = np.array([int(cw[m + 1:].sum()) for m in range(L)], dtype=np.int64)
+    Ka = int(cw.sum())
+    return cw, coff, Ka, Ka + YB
+
+
+def _sym_lower(a):
+    return np.tril(a) + np.tril(a, -1).T
+
+
+def collect_node_blocks(tree, posterior: bool = True) -> List[NodeBlocks]:
+    """All nodes of ``tree`` (a pymra_amd.MRATree built with a device kernel) in level (BFS) order."""
+    topo, pl, spec = tree.topology, tree.plan, tree.kernel
+    if spec is None:
+        raise NotImplementedError("node blocks need a device kernel (KernelSpec); opaque cov callables are not supported here")
+    cw, coff, Ka, ldw = _layout(topo)
+    locs = np.asarray(tree.locs, dtype=np.float64)
+    if locs.ndim == 1:
+        locs = locs.reshape(-1, 1)
+    yv = np.asarray(tree.obs, dtype=np.float64).reshape(-1)
+    R = float(tree.R)
+    n = topo.n_nodes
+    # ---- pass 1: prior basis
+    pl.run(True, False)
+    Wp = pl.buffer(0).reshape(topo.P, ldw)
+    dnode = None
+    Lp = {}
+    for i in range(n):
+        if not topo.node_leaf[i]:
+            Lp[i] = np.tril(pl.node_block(i, P.MRA_BLOCK_LPRIOR))
+    # ---- pass 2: posterior, level-by-level kernels (they write every level's X back into W)
+    Wx = front = None
+    if posterior:
+        pl.set_option(P.MRA_OPT_FUSED, 0)
+        try:
+            pl.run(True, True)
+            Wx = pl.buffer(0).reshape(topo.P, ldw)
+            dnode = pl.buffer(1)
+            front = {i: pl.node_block(i, P.MRA_BLOCK_FRONT) for i in range(n) if not topo.node_leaf[i]}
+        finally:
+            pl.set_option(P.MRA_OPT_FUSED, 1)
+
+    def chain_of(i):
+        c = []
+        while i >= 0:
+            c.append(i)
+            i = int(topo.node_parent[i])
+        return c[::-1]
+
+    out: List[NodeBlocks] = []
+    sub_d = np.zeros(n) if dnode is None else np.array(dnode, dtype=np.float64)
+    if dnode is not None:                                  # the reference's d is cumulative over the subtree (MRANode.py:466-468)
+        for i in range(n - 1, 0, -1):
+            sub_d[int(topo.node_parent[i])] += sub_d[i]
+    for i in range(n):
+        m = int(topo.node_level[i])
+        r0, r1 = int(topo.node_row0[i]), int(topo.node_row1[i])
+        pr = np.arange(r0, r1)
+        pr = pr[topo.perm[pr] >= 0]
+        pr = pr[np.argsort(topo.perm[pr], kind="stable")]          # ascending caller index = the order of Node.locs
+        kq = topo.knot_rows[topo.knot_ptr[i]:topo.knot_ptr[i + 1]]
+        rk = len(kq)
+        nb = NodeBlocks()
+        nb.ID, nb.res, nb.index, nb.leaf = topo.node_ident[i], m, i, bool(topo.node_leaf[i])
+        nb.rows = topo.perm[pr].copy()
+        nb.N = len(pr)
+        nb.kInds = np.searchsorted(nb.rows, np.sort(topo.perm[kq]))
+        chain = chain_of(i)
+        anc = chain[:-1]
+        if not nb.leaf:
+            L = Lp[i][:rk, :rk]
+            nb.B = Wp[pr, coff[m]:coff[m] + rk] @ L.T
+            nb.kInv = L @ L.T
+        else:
+            # residual covariance of the leaf's rows with its own (all not-yet-used) locations
+            Bl = spec.evaluate(locs[topo.perm[pr]], locs[topo.perm[kq]])
+            for a in anc:
+                ma = int(topo.node_level[a])
+                ra = topo.rank(a)
+                Bl = Bl - Wp[pr, coff[ma]:coff[ma] + ra] @ Wp[kq, coff[ma]:coff[ma] + ra].T
+            nb.B = np.asarray(Bl)
+            nb.kInv = nb.B[nb.kInds, :]
+            nb.kInv = 0.5 * (nb.kInv + nb.kInv.T)
+        nb.k = np.linalg.inv(nb.kInv)
+        nb.kC = np.linalg.cholesky(0.5 * (nb.k + nb.k.T))
+        nb.A = nb.omg = nb.kTil = nb.kTilC = nb.BTil = None
+        nb.d = nb.u = None
+        if posterior:
+            if not nb.leaf:
+                F = front[i]
+                cwm = int(cw[m])
+                Lt = np.tril(F[:cwm, :cwm])
+                Zt = F[cwm:, :cwm]
+                Gt = _sym_lower(F[cwm:, cwm:])
+                nf = F.shape[0]
+                G = np.empty((nf, nf))
+                G[:cwm, :cwm] = Lt @ Lt.T - np.eye(cwm)
+                G[cwm:, :cwm] = Zt @ Lt.T
+                G[:cwm, cwm:] = G[cwm:, :cwm].T
+                G[cwm:, cwm:] = Gt + Zt @ Zt.T
+                # front order: own block, then ancestors deepest first, then the y block
+                blocks = [(i, 0, rk)]
+                off = cwm
+                for a in anc[::-1]:
+                    blocks.append((a, off, topo.rank(a)))
+                    off += int(cw[int(topo.node_level[a])])
+                ycol = off
+                Ls = {a: (Lp[a][:rr, :rr]) for a, _, rr in blocks}
+                byres = {int(topo.node_level[a]): (a, o, rr) for a, o, rr in blocks}
+                nb.A = [[None] * (m + 1) for _ in range(m + 1)]
+                nb.omg = [None] * (m + 1)
+                for k in range(m + 1):
+                    ak, ok, rrk = byres[k]
+                    nb.omg[k] = Ls[ak] @ G[ok:ok + rrk, ycol]
+                    for l in range(m + 1):
+                        al, ol, rrl = byres[l]
+                        nb.A[k][l] = Ls[ak] @ G[ok:ok + rrk, ol:ol + rrl] @ Ls[al].T
+                LL = Lp[i][:rk, :rk] @ Lt[:rk, :rk]
+                LLi = sla.solve_triangular(LL, np.eye(rk), lower=True)
+                nb.kTil = LLi.T @ LLi
+                X = Wx[pr, coff[m]:coff[m] + rk]
+                nb.BTil = X @ LL.T
+                nb.u = float(Gt[ycol - cwm, ycol - cwm])
+            else:
+                yo = np.where(topo.perm[pr] >= 0, yv[topo.perm[pr]], np.nan)
+                o = np.isfinite(yo)
+                Bo = nb.B[o]
+                Amm = Bo.T @ Bo / R
+                nb.A = Amm
+                nb.omg = Bo.T @ yo[o] / R
+                nb.kTil = np.linalg.inv(nb.kInv + Amm)
+                nb.BTil = nb.B
+                nb.u = float(-nb.omg @ nb.kTil @ nb.omg + yo[o] @ yo[o] / R)
+            ev, V = np.linalg.eigh(0.5 * (nb.kTil + nb.kTil.T))            # MRANode.py:504-507
+            nb.kTilC = V @ np.diag(np.sqrt(np.abs(ev)))
+            nb.d = float(sub_d[i])
+        out.append(nb)
+    return out
+
+
+def basis_functions_matrix(tree, distr="prior", groupByResolution=False, order="root", timesKC=False):
+    """``MRATree.getBasisFunctionsMatrix`` (pyMRA/MRATree.py:445-511): ``[B_root | blockdiag(level 1) | ...]``
+    with one column per knot, ``B`` being the prior basis ``B_j`` or the posterior ``BTil_j[res_j]``, optionally
+    times ``kC`` / ``kTilC`` so that ``B B^T`` is the (prior / posterior) MRA covariance matrix.
+
+    Every node's block is placed at the caller rows of that node.  Within a level the node blocks are ordered
+    as the reference orders them: by smallest x-coordinate for ``order='root'`` (stable; in 1-D this is the
+    left-to-right order that makes the reference's ``block_diag`` line up with the root's rows), in tree order
+    for ``order='leaves'``, where rows are additionally permuted into depth-first leaf order
+    (``Node.getOrderFromLeaves``, pyMRA/MRANode.py:134-159)."""
+    if distr not in ("prior", "posterior"):
+        raise ValueError("distr must be 'prior' or 'posterior'")
+    topo = tree.topology
+    nodes = collect_node_blocks(tree, posterior=(distr == "posterior"))
+    N = topo.N
+    locs = np.asarray(tree.locs, dtype=np.float64)
+    if locs.ndim == 1:
+        locs = locs.reshape(-1, 1)
+    if order == "leaves":
+        real = topo.perm[topo.perm >= 0]
+        _, first = np.unique(real, return_index=True)
+        row_order = real[np.sort(first)]
+    else:
+        row_order = np.arange(N)
+    inv = np.empty(N, dtype=np.int64)
+    inv[row_order] = np.arange(len(row_order))
+    mats = []
+    for m in range(topo.n_levels):
+        lvl = [nb for nb in nodes if nb.res == m]
+        if not lvl:
+            continue
+        if order == "root" and m > 0:
+            key = np.array([locs[nb.rows, 0].min() if nb.N else np.inf for nb in lvl])
+            lvl = [lvl[t] for t in np.argsort(key, kind="stable")]
+        width = sum(len(nb.kInds) for nb in lvl)
+        Bm = np.zeros((N, width))
+        c = 0
+        for nb in lvl:
+            blk = nb.B if distr == "prior" else nb.BTil
+            if timesKC:
+                blk = blk @ (nb.kC if distr == "prior" else nb.kTilC)
+            Bm[inv[nb.rows], c:c + blk.shape[1]] = blk
+            c += blk.shape[1]
+        mats.append(np.matrix(Bm))
+    if groupByResolution:
+        return mats
+    return np.matrix(np.hstack([np.asarray(b) for b in mats]))

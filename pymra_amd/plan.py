@@ -18,6 +18,9 @@ MRA_RUN_PREDICT = 2
 MRA_RUN_SPLIT = 4
 MRA_KERNEL_HOST = 100
 MRA_OPT_KERNEL_TIMING = 1
+MRA_OPT_FUSED = 2
+MRA_OPT_GEMM_LDS = 3
+MRA_BLOCK_W_ROWS, MRA_BLOCK_LPRIOR, MRA_BLOCK_FRONT, MRA_BLOCK_LEAF = 0, 1, 2, 3
 
 ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4: "MRA_ERR_STATE",
              -5: "MRA_ERR_COMM"}
@@ -26,7 +29,7 @@ ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4
 EXPORTS = [
     "mra_device_count", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
     "mra_plan_set_kernel", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
-    "mra_get_buffer", "mra_get_timers", "mra_plan_set_option", "mra_kernel_family_count",
+    "mra_get_buffer", "mra_get_node_block", "mra_get_timers", "mra_plan_set_option", "mra_kernel_family_count",
     "mra_get_kernel_stats", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
     "mra_run_resume", "mra_last_error", "mra_version",
@@ -75,6 +78,7 @@ def load_library():
         "mra_get_likelihood": (C.c_int, [vp, C.POINTER(dbl), C.POINTER(dbl)]),
         "mra_get_predict": (C.c_int, [vp, vp, vp]),
         "mra_get_buffer": (C.c_int, [vp, C.c_int, vp, i64, C.POINTER(i64)]),
+        "mra_get_node_block": (C.c_int, [vp, i32, C.c_int, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "mra_get_timers": (C.c_int, [vp, vp, C.c_int]),
         "mra_plan_set_option": (C.c_int, [vp, C.c_int, i64]),
         "mra_kernel_family_count": (C.c_int, []),
@@ -256,6 +260,15 @@ class HipPlan:
         self._check(self.lib.mra_get_buffer(self._h, what, None, 0, C.byref(n)))
         out = np.empty(n.value)
         self._check(self.lib.mra_get_buffer(self._h, what, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def node_block(self, node, what):
+        """Raw per-node device block (include/mra_hip.h: MRA_BLOCK_*), as a 2-D array."""
+        nr, nc = C.c_int64(), C.c_int64()
+        self._check(self.lib.mra_get_node_block(self._h, int(node), int(what), None, 0, C.byref(nr), C.byref(nc)))
+        out = np.empty((nr.value, nc.value))
+        if out.size:
+            self._check(self.lib.mra_get_node_block(self._h, int(node), int(what), _ptr(out), out.size, C.byref(nr), C.byref(nc)))
         return out
 
     def timers(self):

@@ -5,6 +5,7 @@ Run only in the build container, where /root/reference exists:
 
     python tests/golden/make_golden.py [case ...]        # default: every case but c3
     python tests/golden/make_golden.py c3                # ~30 min, 2.4 GB
+    python tests/golden/make_golden.py --nodes [case ...]  # per-node blocks of the tiny cases -> <case>_nodes.npz
 
 The fixtures are data only (inputs or their recipe, the tree the reference built, and the
 reference's outputs); no reference code is stored.  The reference imports the third-party
@@ -190,8 +191,61 @@ def run_case(name, MRATree, MRANode, rmt):
     print("%-6s N=%-8d nodes=%-5d lik=%.10f wall=%.1fs" % (name, N, len(rec), lik, wall), flush=True)
 
 
+NODE_CASES = ["kat2", "kat3", "c1", "u3", "g32"]
+
+
+def run_case_nodes(name, MRATree, MRANode, rmt):
+    """Per-node blocks of a tiny case -> <name>_nodes.npz: for every node (keyed by its position in the
+    reference's construction order) what the reference holds right after calculatePosterior
+    (pyMRA/MRANode.py:403-523): B, kInv, kC, kTil, kTilC, A[res][res], omg[res] (the children's omgTil summed, or
+    the leaf's own B^T H^T obs / R), BTil[res], d, u, mean, var.  The main fixture <name>.npz is not touched."""
+    c = CASES[name]
+    locs, y_obs, _ = make_inputs(c)
+    rcov = {"exp": lambda a, b: rmt.ExpCovFun(a, b, l=c["l"]),
+            "m32": lambda a, b: rmt.Matern32(a, b, l=c["l"], sig=c["sig"])}[c["kern"]]
+    out = {}
+    order = []
+    orig_prior = MRANode.Node.calculatePrior
+    orig_post = MRANode.Node.calculatePosterior
+
+    def spy_prior(self, cov):
+        order.append(self.ID)
+        return orig_prior(self, cov)
+
+    def spy_post(self, obs, R):
+        res = orig_post(self, obs, R)
+        t = order.index(self.ID)
+        a = lambda x: np.array(x, dtype=np.float64)
+        if self.leaf:
+            oi = np.array(np.isfinite(obs)).ravel()
+            omg = a(self._getB_lk(self.res))[oi].T @ a(obs)[oi] / R
+        else:
+            omg = sum(a(ch.omgTil[self.res]) for ch in self.children)
+        blk = dict(B=a(self.B), kInv=a(self.kInv), kC=a(self.kC), kTil=a(self.kTil), kTilC=a(self.kTilC),
+                   Amm=a(self.A[self.res][self.res]), omg=a(omg).ravel(), BTil=a(self.BTil[self.res]),
+                   d=a(self.d).ravel()[:1], u=a(self.u).ravel()[:1], mean=a(self.mean).ravel(), var=a(self.var).ravel())
+        for k, v in blk.items():
+            out["n%d_%s" % (t, k)] = v
+        return res
+    MRANode.Node.calculatePrior = spy_prior
+    MRANode.Node.calculatePosterior = spy_post
+    try:
+        MRATree(locs, c["r"], rcov, y_obs, c["R"], M=c["M"], J=c["J"])
+    finally:
+        MRANode.Node.calculatePrior = orig_prior
+        MRANode.Node.calculatePosterior = orig_post
+    out["node_ident"] = np.array(order)
+    out["params"] = json.dumps(c)
+    np.savez_compressed(os.path.join(HERE, name + "_nodes.npz"), **out)
+    print("%-6s per-node blocks of %d nodes" % (name, len(order)), flush=True)
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or DEFAULT
+    args = sys.argv[1:]
     MRATree, MRANode, rmt = _import_reference()
-    for nm in names:
-        run_case(nm, MRATree, MRANode, rmt)
+    if args and args[0] == "--nodes":
+        for nm in (args[1:] or NODE_CASES):
+            run_case_nodes(nm, MRATree, MRANode, rmt)
+    else:
+        for nm in (args or DEFAULT):
+            run_case(nm, MRATree, MRANode, rmt)

@@ -84,3 +84,44 @@ def test_subtree_sample_is_the_same_arithmetic():
     top = int(t.level_ptr[1])                               # first level-1 node
     n, secs, tm = run_subtree_sample(t, cs["locs"], cs["covfun"], cs["y_obs"], cs["c"]["R"], top, do_gc=False)
     assert n == 21 and secs > 0 and tm["posterior"] > 0
+
+
+@pytest.mark.parametrize("name", ["kat2", "kat3", "c1", "g32"])
+def test_faithful_oracle_per_node_blocks_match_the_reference(name):
+    """Every intermediate block of every node (B, kInv, kTil, A[res][res], omg[res], BTil[res], d, u) against what
+    the reference held on its Node objects (tests/golden/<name>_nodes.npz, pyMRA/MRANode.py:384-391, 426-511)."""
+    cs = K.load_case(name)
+    t = cs["topo"]
+    nodes = {}
+    run_faithful(t, cs["locs"], cs["covfun"], cs["y_obs"], cs["c"]["R"], keep_nodes=nodes)
+    gold = K.load_node_goldens(name)
+    assert len(gold) == t.n_nodes
+    for i in range(t.n_nodes):
+        g, s = gold[t.node_ident[i]], nodes[i]
+        m = int(t.node_level[i])
+        pr = K.node_real_rows(t, i) - t.node_row0[i]
+        sc = max(1.0, float(np.abs(g["Amm"]).max()))
+        assert g["B"].shape == (len(pr), s.B.shape[1])
+        assert np.max(np.abs(s.B[pr] - g["B"])) < 1e-11
+        assert np.max(np.abs(s.kInv - g["kInv"])) < 1e-11
+        assert np.max(np.abs(s.A[m][m] - g["Amm"])) < 1e-9 * sc
+        assert np.max(np.abs(np.ravel(s.omg[m]) - g["omg"])) < 1e-9 * max(1.0, float(np.abs(g["omg"]).max()))
+        assert np.max(np.abs(s.kTil - g["kTil"])) < 1e-9 * max(1.0, float(np.abs(g["kTil"]).max()))
+        assert np.max(np.abs(s.BTil[m][pr] - g["BTil"])) < 1e-9
+        assert abs(float(np.ravel(s.d)[0]) - float(g["d"][0])) < 1e-8 * max(1.0, abs(float(g["d"][0])))
+        assert abs(float(np.ravel(s.u)[0]) - float(g["u"][0])) < 1e-8 * max(1.0, abs(float(g["u"][0])))
+
+
+def test_data_loader_mirrors_the_reference():
+    """pyMRA/DataLoader.py:5-19: sizes, NaN counts (SURVEY section 2.1 #7) and the KAT4 inputs."""
+    import pymra_amd.DataLoader as dl
+    y, locs, y_obs = dl.load_data("small", True)
+    assert y.shape == (10, 10) and locs.shape == (100, 2) and y_obs.shape == (100, 1) and int(np.isnan(y_obs).sum()) == 14
+    g = np.load(K.os.path.join(K.GOLD, "kat4.npz"))
+    assert np.array_equal(locs, g["locs"]) and np.array_equal(y_obs, g["y_obs"], equal_nan=True)
+    y, locs, y_obs = dl.load_data("large", include_truth=True)
+    assert y.shape == (100, 100) and locs.shape == (10000, 2) and int(np.isnan(y_obs).sum()) == 1440
+    yo, lo = dl.load_data("small")
+    assert yo.shape == (100, 1) and lo.shape == (100, 2)
+    with pytest.raises(ValueError):
+        dl.load_data("medium")

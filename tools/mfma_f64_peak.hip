@@ -42,6 +42,25 @@ __global__ __launch_bounds__(256) void k_mfma(double* out, const double* __restr
     if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (512 flop), one f64 per lane for A, B and D
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma4(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+    double acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    double a = in[gid & 4095], b = in[(gid * 7 + 13) & 4095];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[gid] = s;
+    if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
+}
+
 // VALU only: 16 independent v_fma_f64 chains
 __global__ __launch_bounds__(256) void k_vfma(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +209,8 @@ int main(int argc, char** argv) {
         run(k_mfma<1, 0>, 256, 256, "mfma_f64_16x16x4, 1 wave/SIMD, 1 dependent accumulator", 1.0 * iters, 2048.0 / 64, 1, 3);
         run(k_mfma<1, 0>, 256 * 4, 256, "mfma_f64_16x16x4, 4 waves/SIMD, 1 dependent accumulator", 1.0 * iters, 2048.0 / 64, 4, 3);
         run(k_mfma<2, 0>, 256, 256, "mfma_f64_16x16x4, 1 wave/SIMD, 2 accumulators", 2.0 * iters, 2 * 2048.0 / 64, 1, 3);
+        run(k_mfma4<8>, 256 * 4, 256, "mfma_f64_4x4x4_4b, 4 waves/SIMD, 8 accumulators", 8.0 * iters, 8 * 512.0 / 64, 4, 3);
+        run(k_mfma4<8>, 256, 256, "mfma_f64_4x4x4_4b, 1 wave/SIMD, 8 accumulators", 8.0 * iters, 8 * 512.0 / 64, 1, 3);
         run(k_vfma, 256 * 8, 256, "v_fma_f64 only, 8 waves/SIMD, 16 chains", 0, 32.0, 8, 3);
         run(k_vfma, 256 * 2, 256, "v_fma_f64 only, 2 waves/SIMD, 16 chains", 0, 32.0, 2, 3);
         // co-issue inside one wave: per MFMA 2 / 4 / 8 independent v_fma_f64
