@@ -16,10 +16,17 @@ N > 1: strong scaling - the same tree, level-s subtrees sharded over the ranks, 
 of the level s-1 fronts per step (pymra_amd/sharding.py); torch.distributed (gloo) is used only for
 the rendezvous, the barriers and the max-over-ranks of the timings.
 
-Extra objects in the JSON line: "roofline" (dominant kernel, hipEvent-timed inside the timed steps),
-"cpu_baseline" (N=1, rank 0: the faithful NumPy/SciPy restatement of the reference timed on a
-bounded sample of the same tree), "host" (end-to-end constructor wall-clock incl. the host tree
-build, for the getLikelihood()+predict() wall-clock half of the metric).
+"value" (= "value_resident") is the device pass with tree, locations and observations resident in HBM - what an MLE
+loop pays per evaluation; "value_end_to_end" is the same node count over the wall-clock of the drop-in constructor
+MRATree(...) + getLikelihood() + predict() (host tree replay + uploads + device pass + download), the quantity
+SURVEY.md section 8(d) defines for the reference.  Extra objects in the JSON line: "roofline" (dominant kernel,
+hipEvent-timed inside the timed steps; "peak" is the datasheet FP64 matrix rate, "peak_measured" the rate of an
+LDS-fed register-blocked v_mfma_f64_16x16x4 loop on this GPU, profiles/r02_mfma_f64_microbench.txt), "cpu_baseline"
+(N=1, rank 0: the faithful NumPy/SciPy restatement of the reference timed on a bounded sample of the same tree, with
+and without the reference's per-node gc.collect() and with one BLAS thread), "host" (set-up timings).
+
+--config c5 (BASELINE config 5 geometry, 2048^2 grid, M=8, r0=64) adds "mle": Nelder-Mead objective evaluations
+per second on the resident plan (likelihood-only passes with a new kernel parameter each).
 """
 import argparse
 import json
@@ -33,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (= vector) peak; DESIGN.md section 5
+FP64_MFMA_MEASURED_TFLOPS = 76.5  # LDS-fed 2x2 register-blocked v_mfma_f64_16x16x4 loop, 2 workgroups/CU (tools/mfma_f64_4x4.hip)
 HBM_PEAK_GBS = 8000.0
 
 CONFIGS = {
@@ -57,7 +65,9 @@ def make_inputs(c):
 
 def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
     """Faithful restatement of the reference's per-node work (oracle/mra_faithful.py) on a bounded
-    sample: one level-3 subtree of the same tree (85 nodes incl. 64 leaves at c3)."""
+    sample: one level-3 subtree of the same tree (85 nodes incl. 64 leaves at c3).  Three figures, as BASELINE.md
+    section 3 asks: with the reference's per-node gc.collect() (MRANode.py:111) on the default BLAS thread pool (the
+    headline "value"), the same without gc.collect(), and with one BLAS thread (the small LAPACK calls oversubscribe)."""
     import pymra_amd.MRATools as mt
     from oracle.mra_faithful import run_subtree_sample
     cov = (lambda a, b: mt.Matern32(a, b, l=c["l"], sig=c["sig"])) if c["kern"] == "m32" else \
@@ -71,12 +81,16 @@ def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
             level = m
     top = int(topo.level_ptr[level])
     n, secs, tm = run_subtree_sample(topo, locs, cov, y_obs, c["R"], top, do_gc=True)
+    n2, secs_nogc, _ = run_subtree_sample(topo, locs, cov, y_obs, c["R"], top, do_gc=False)
+    secs_1t = None
     # threads actually used: the BLAS/LAPACK pool NumPy and SciPy run on (the Python loop itself is serial)
     cores = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         pools = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
         cores = max(pools) if pools else None
+        with threadpool_limits(limits=1, user_api="blas"):
+            _, secs_1t, _ = run_subtree_sample(topo, locs, cov, y_obs, c["R"], top, do_gc=False)
     except Exception:
         pass
     if not cores:
@@ -88,7 +102,30 @@ def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
             "sample": "subtree of level-%d node %d of the same tree: %d nodes (%.1f s; prior %.1f s, posterior %.1f s, "
                       "per-node gc.collect %.1f s as in MRANode.py:111), NumPy/SciPy default BLAS threads"
                       % (level, top, n, secs, tm["prior"], tm["posterior"], tm["gc"]),
-            "seconds": secs, "nodes": n}
+            "seconds": secs, "nodes": n,
+            "variants": {"without_gc_collect": {"value": n2 / secs_nogc, "seconds": secs_nogc, "cores": cores},
+                         "one_blas_thread_without_gc_collect": ({"value": n2 / secs_1t, "seconds": secs_1t, "cores": 1}
+                                                                if secs_1t else None)}}
+
+
+def mle_throughput(pl, c, kind, evals=24):
+    """Nelder-Mead over the range parameter on the resident plan (README.md:96-104, tests/test-param-est.py:81-123):
+    every objective call is one likelihood-only device pass with new kernel parameters."""
+    import scipy.optimize as opt
+    calls = []
+
+    def obj(p):
+        pl.set_kernel(kind, float(abs(p[0])) + 1e-3, c["sig"], 1.0)
+        pl.run(True, False)
+        d, u = pl.likelihood()
+        calls.append(d + u)
+        return d + u
+    t0 = time.perf_counter()
+    res = opt.minimize(obj, [c["l"]], method="nelder-mead", options={"xatol": 1e-3, "maxfev": evals, "disp": False})
+    dt = time.perf_counter() - t0
+    pl.set_kernel(kind, c["l"], c["sig"], 1.0)
+    return {"objective_evaluations": len(calls), "seconds": dt, "evaluations_per_s": len(calls) / dt,
+            "ms_per_evaluation": 1e3 * dt / len(calls), "kappa_start": c["l"], "kappa_last": float(abs(res.x[0])) + 1e-3}
 
 
 def main():
@@ -99,6 +136,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--likelihood-only", action="store_true")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="with --exchange rccl: if RCCL cannot initialise, re-plan onto the host/gloo exchange instead of failing "
+                         "(the line then carries \"exchange_fallback\": true)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
                     help="transport of the one front all-reduce for --gpus > 1: RCCL on the device (default) or "
                          "host export/import + torch.distributed gloo (rehearsal on a box with fewer GPUs than ranks)")
@@ -142,6 +182,7 @@ def main():
     pl.set_kernel(kind, c["l"], c["sig"], 1.0)
     host_allreduce = None
     exchange = args.exchange
+    fallback = False
     if world > 1 and exchange == "rccl":
         ok = 1
         try:
@@ -161,8 +202,12 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
+            if not args.allow_gloo_fallback:
+                raise SystemExit("RCCL could not initialise on every rank; refusing to measure the host exchange instead "
+                                 "(pass --allow-gloo-fallback or --exchange gloo to do that on purpose)")
             # every rank falls back together: host export/import + gloo all-reduce of the same buffer
             exchange = "gloo (RCCL unavailable)"
+            fallback = True
             pl.close()
             pl = P.HipPlan(local, local_rank)
             pl.set_locs(locs); pl.set_obs(y_obs, c["R"]); pl.set_kernel(kind, c["l"], c["sig"], 1.0)
@@ -241,17 +286,22 @@ def main():
             except Exception:
                 pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "peak_measured": FP64_MFMA_MEASURED_TFLOPS,
+                "frac_of_measured": ach / FP64_MFMA_MEASURED_TFLOPS, "traffic": traffic,
                 "traffic_raw_counters": traffic_raw, "traffic_source": traffic_src,
                 "avg_launch_ms": dom_ms, "flop_per_launch": dom_fl,
                 "kernels": [{"name": k["name"], "launches_per_step": k["launches"] / args.steps,
                              "ms_per_step": k["ms"] / args.steps,
                              "tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12) if k["ms"] > 0 else 0.0}
                             for k in kacc if k["launches"]]}
+        whole_flop = sum(k["flops"] for k in kacc) / args.steps
         out = {
-            "metric": "MRA nodes/sec (prior+posterior+likelihood+predict pass), 1024^2 grid M=6 J=4 r0=32"
-                      if args.config == "c3" else "MRA nodes/sec, %s" % args.config,
+            "metric": "MRA nodes/sec, resident device pass (prior+posterior+likelihood+predict with tree and data in HBM), "
+                      "1024^2 grid M=6 J=4 r0=32" if args.config == "c3" else
+                      "MRA nodes/sec, resident device pass, %s" % args.config,
             "value": n_nodes * args.steps / elapsed_plain, "unit": "nodes/s", "n_gpus": world,
+            "value_resident": n_nodes * args.steps / elapsed_plain, "value_end_to_end": None,
+            "whole_pass": {"flop_algorithmic": whole_flop, "tflops": whole_flop / (1e-3 * 1e3 * elapsed_plain / args.steps) / 1e12},
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_plain / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -260,12 +310,15 @@ def main():
                        "frac_obs": c["frac"], "R": c["R"], "nodes": n_nodes,
                        "mode": "likelihood" if args.likelihood_only else "likelihood+predict",
                        "parallelism": ("subtree-shard x%d, 1 all-reduce (%s)" % (world, exchange)) if world > 1 else "single GPU"},
+            "exchange_fallback": fallback,
             "likelihood": d + u,
             "ms_per_step_with_kernel_events": 1e3 * elapsed / args.steps,
             "device_phase_ms": timers,
             "roofline": roof,
             "host": {"input_synthesis_s": t1 - t0, "tree_build_s": t2 - t1, "plan_and_upload_s": t3 - t2},
         }
+    if rank == 0 and world == 1 and args.config == "c5":
+        out["mle"] = mle_throughput(pl, c, kind)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, locs, y_obs, c)
         # end-to-end constructor wall-clock of the drop-in API (host tree build + H2D + device pass + D2H)
@@ -278,6 +331,7 @@ def main():
         tree = MRATree(locs, c["r"], cov, y_obs, c["R"], M=c["M"], J=c["J"])
         lik = tree.getLikelihood(); xP, sdP = tree.predict()
         out["host"]["constructor_getLikelihood_predict_wall_s"] = time.perf_counter() - tA
+        out["value_end_to_end"] = n_nodes / out["host"]["constructor_getLikelihood_predict_wall_s"]
         out["host"]["speedup_vs_cpu_baseline_nodes_per_s"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))

@@ -61,10 +61,33 @@ enum KFam {
     KF_PRIOR_RESID = 0, KF_PRIOR_CHOL, KF_PRIOR_TRSM, KF_LEAF_RESID, KF_LEAF_CHOL, KF_LEAF_SYRK,
     KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
 };
-static const char* kfam_name[KF_COUNT] = {
-    "k_gemm_nt<COV> prior resid", "k_panel_chol prior / fused knot pass", "k_trsm_rows prior / fused prior cascade", "k_gemm_nt<COV> leaf resid",
-    "k_panel_chol leaf", "k_gemm_nt<SET> leaf syrk", "k_gemm_nt<SUB> leaf update", "k_panel_chol front",
-    "k_gemm_nt<SUB> front schur", "k_trsm_rows predict", "k_gemm_nt<SUB> predict update / fused predict cascade", "small kernels"};
+// family names = the kernels that actually run (rocprofv3 kernel names), by path: [0] fused cascades on regular trees,
+// [1] general level-by-level path.  tools/summarize_profiles.py maps the trace's kernel names onto the same strings.
+static const char* kfam_name[2][KF_COUNT] = {
+    {"k_gemm_nt_lds<COV> prior residual (unused on the fused path)",
+     "k_prior_cascade knot pass (knot rows + kInv + Cholesky, one launch per level)",
+     "k_prior_cascade row pass (W of all levels, Ut scatter)",
+     "k_gemm_nt_lds<COV> leaf residual V[S,o] and C",
+     "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
+     "k_gemm_nt<SET> parent fronts from Ut (segmented SYRK)",
+     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_panel_chol front partial Cholesky",
+     "k_gemm_nt<SUB> front Schur complement",
+     "k_trsm_rows2 predict (unused on the fused path)",
+     "k_predict_cascade (all levels, mean/var)",
+     "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"},
+    {"k_gemm_nt_lds<COV> prior residual per level",
+     "k_panel_chol prior kInv Cholesky per level",
+     "k_trsm_rows2 prior W = R L^-T per level",
+     "k_gemm_nt_lds<COV> leaf residual V[S,o] and C",
+     "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
+     "k_gemm_nt<SET> leaf / parent SYRK",
+     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_panel_chol front partial Cholesky",
+     "k_gemm_nt<SUB> front Schur complement",
+     "k_trsm_rows2 predict X = W Lt^-T per level",
+     "k_gemm_nt_lds<SUB> predict update per level",
+     "small kernels (k_assemble, k_gather_kinv, k_leaf_moments, k_sum_dnode, ...)"}};
 
 template <class T>
 struct DevVec {
@@ -1491,7 +1514,8 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
 
 int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int* launches, double* ms, double* flops) {
     if (!pl || which < 0 || which >= KF_COUNT) return MRA_ERR_INVALID;
-    if (name && name_cap > 0) { strncpy(name, kfam_name[which], name_cap - 1); name[name_cap - 1] = 0; }
+    const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
+    if (name && name_cap > 0) { strncpy(name, kfam_name[fused ? 0 : 1][which], name_cap - 1); name[name_cap - 1] = 0; }
     if (launches) *launches = pl->kstat[which].launches;
     if (ms) *ms = pl->kstat[which].ms;
     if (flops) *flops = pl->kstat[which].flops;

@@ -280,9 +280,9 @@ class HipPlan:
     def kernel_stats(self):
         res = []
         for k in range(self.lib.mra_kernel_family_count()):
-            name = C.create_string_buffer(96)
+            name = C.create_string_buffer(128)
             n, ms, fl = C.c_int(), C.c_double(), C.c_double()
-            self._check(self.lib.mra_get_kernel_stats(self._h, k, name, 96, C.byref(n), C.byref(ms), C.byref(fl)))
+            self._check(self.lib.mra_get_kernel_stats(self._h, k, name, 128, C.byref(n), C.byref(ms), C.byref(fl)))
             res.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
         return res
 

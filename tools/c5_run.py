@@ -32,4 +32,11 @@ for rep in range(3):
 ta = time.time(); pl.run(True, False); tb = time.time()
 d2, u2 = pl.likelihood()
 print("likelihood-only %.1f ms, rel diff to full %.2e ; nodes/s (full) %.0f" % (1e3 * (tb - ta), abs(d2 + u2 - d - u) / abs(d + u), topo.n_nodes / (1e-3 * pl.timers()["total_ms"])), flush=True)
-mean, var = pl.predict() if False else (None, None)
+pl.set_option(1, 1)
+for pred in (True, False):
+    pl.run(True, pred)
+    print("per-kernel (likelihood%s):" % ("+predict" if pred else " only"))
+    for k in pl.kernel_stats():
+        if k["launches"]:
+            print("   %-60s %3d launches %9.3f ms %7.2f TFLOP/s" % (k["name"], k["launches"], k["ms"], k["flops"] / max(k["ms"], 1e-9) / 1e9))
+    print("   phases", {k: round(v, 2) for k, v in pl.timers().items()})

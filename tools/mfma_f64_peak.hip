@@ -42,6 +42,59 @@ __global__ __launch_bounds__(256) void k_mfma(double* out, const double* __restr
     if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
 }
 
+// as k_mfma<4,0> but every MFMA of a round reads a different (A, B) register pair, like a 2x2 register-blocked GEMM tile
+// (a0 b0, a0 b1, a1 b0, a1 b1): with the SAME two source registers in every instruction the pipe issues only every ~98 cycles,
+// with varying sources every ~64-70 - the register-blocked form is the one real kernels have
+__global__ __launch_bounds__(256) void k_mfma_blk(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+    d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+    }
+    const d4 s = c00 + c01 + c10 + c11;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[gid] = s[0] + s[1] + s[2] + s[3];
+    if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
+}
+// one accumulator, alternating source registers: the dependent-chain rate of real code
+__global__ __launch_bounds__(256) void k_mfma_dep(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+    d4 c = {0, 0, 0, 0};
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[gid] = c[0] + c[1] + c[2] + c[3];
+    if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
+}
+// two accumulators, alternating
+__global__ __launch_bounds__(256) void k_mfma_dep2(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+    d4 c = {0, 0, 0, 0}, e = c;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, e, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c, 0, 0, 0);
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, e, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    const d4 s = c + e;
+    out[gid] = s[0] + s[1] + s[2] + s[3];
+    if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
+}
+
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (512 flop), one f64 per lane for A, B and D
 template <int NACC>
 __global__ __launch_bounds__(256) void k_mfma4(double* out, const double* __restrict__ in, int iters, Stamp* st) {
@@ -209,6 +262,13 @@ int main(int argc, char** argv) {
         run(k_mfma<1, 0>, 256, 256, "mfma_f64_16x16x4, 1 wave/SIMD, 1 dependent accumulator", 1.0 * iters, 2048.0 / 64, 1, 3);
         run(k_mfma<1, 0>, 256 * 4, 256, "mfma_f64_16x16x4, 4 waves/SIMD, 1 dependent accumulator", 1.0 * iters, 2048.0 / 64, 4, 3);
         run(k_mfma<2, 0>, 256, 256, "mfma_f64_16x16x4, 1 wave/SIMD, 2 accumulators", 2.0 * iters, 2 * 2048.0 / 64, 1, 3);
+        run(k_mfma_blk, 256, 256, "mfma_f64_16x16x4 2x2 register block, 1 wave/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 1, 3);
+        run(k_mfma_blk, 256 * 2, 256, "mfma_f64_16x16x4 2x2 register block, 2 waves/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 2, 3);
+        run(k_mfma_blk, 256 * 4, 256, "mfma_f64_16x16x4 2x2 register block, 4 waves/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 4, 3);
+        run(k_mfma_dep, 256, 256, "mfma_f64_16x16x4 ONE accumulator, varying sources, 1 wave/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 1, 3);
+        run(k_mfma_dep, 256 * 2, 256, "mfma_f64_16x16x4 ONE accumulator, varying sources, 2 waves/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 2, 3);
+        run(k_mfma_dep2, 256, 256, "mfma_f64_16x16x4 TWO accumulators, varying sources, 1 wave/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 1, 3);
+        run(k_mfma_dep2, 256 * 2, 256, "mfma_f64_16x16x4 TWO accumulators, varying sources, 2 waves/SIMD", 4.0 * iters, 4 * 2048.0 / 64, 2, 3);
         run(k_mfma4<8>, 256 * 4, 256, "mfma_f64_4x4x4_4b, 4 waves/SIMD, 8 accumulators", 8.0 * iters, 8 * 512.0 / 64, 4, 3);
         run(k_mfma4<8>, 256, 256, "mfma_f64_4x4x4_4b, 1 wave/SIMD, 8 accumulators", 8.0 * iters, 8 * 512.0 / 64, 1, 3);
         run(k_vfma, 256 * 8, 256, "v_fma_f64 only, 8 waves/SIMD, 16 chains", 0, 32.0, 8, 3);

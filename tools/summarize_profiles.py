@@ -15,17 +15,20 @@ if ks:
     shutil.copy(ks, os.path.join(dst, tag + "_rocprofv3_kernel_stats.csv"))
 
 def family(name, grid, maxgrid):
-    """rocprof kernel name (+ grid) -> bench.py kernel family name"""
+    """rocprof kernel name (+ grid) -> bench.py kernel family name (mra_plan.hip kfam_name[0], the fused path)"""
     if name.startswith("void k_prior_cascade"):
-        return "k_trsm_rows prior / fused prior cascade" if grid == maxgrid.get("cascade") else "k_panel_chol prior / fused knot pass"
-    if name.startswith("void k_predict_cascade"): return "k_gemm_nt<SUB> predict update / fused predict cascade"
-    if name.startswith("void k_gemm_nt_lds<2"): return "k_gemm_nt<COV> leaf resid" if grid == maxgrid.get("cov") else "small kernels"
-    if name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt<SUB> leaf update"
-    if name.startswith("void k_gemm_nt<0"): return "k_gemm_nt<SET> leaf syrk"
-    if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front schur"
-    if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_panel_chol leaf"
-    if name.startswith("k_panel_chol"): return "k_panel_chol front"
-    return "small kernels"
+        return "k_prior_cascade row pass (W of all levels, Ut scatter)" if grid == maxgrid.get("cascade") else \
+               "k_prior_cascade knot pass (knot rows + kInv + Cholesky, one launch per level)"
+    if name.startswith("void k_predict_cascade"): return "k_predict_cascade (all levels, mean/var)"
+    if name.startswith("void k_gemm_nt_lds<2"): return "k_gemm_nt_lds<COV> leaf residual V[S,o] and C" if grid == maxgrid.get("cov") else SMALL
+    if name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut"
+    if name.startswith("void k_gemm_nt<0"): return "k_gemm_nt<SET> parent fronts from Ut (segmented SYRK)"
+    if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front Schur complement"
+    if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)"
+    if name.startswith("k_panel_chol"): return "k_panel_chol front partial Cholesky"
+    return SMALL
+
+SMALL = "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"
 
 # per-family launch durations from the kernel trace of the --stats run (the stats CSV aggregates by kernel NAME, and one
 # name can serve two families: k_prior_cascade is both the knot pass and the row cascade): these are the averages to
