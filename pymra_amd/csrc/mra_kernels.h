@@ -209,16 +209,62 @@ __device__ __forceinline__ bool xcd_problem_tile(unsigned G, unsigned nprob, uns
     return prob < nprob;
 }
 
+// The descriptor is read field by field through a wave-uniform pointer (scalar loads into SGPRs).  A by-value copy
+// whose address escapes (a by-reference lambda capture, pb.segs[sg]) lives in scratch memory: every pb.* access of
+// the epilogue was a scratch load (176 B per lane).  __launch_bounds__(256, 4) keeps the kernel within 128
+// registers: with the full 512 the compiler parks the accumulators in AGPRs and copies all 32 registers of them to
+// VGPRs and back around every K-step (v_accvgpr_read/write: 64 VALU moves per 16 MFMAs).
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
+__device__ __forceinline__ void gemm_nt_emit(const GemmProb* __restrict__ pp, const KernelParams& kp, d4 acc, int mb, int nb, int bcol, int r, int q) {
+    const int col = nb + r;
+    double* const C = pp->C;
+    const long ldc = pp->ldc;
+    double xb[DIM];
+    if (EPI == EPI_COV) {
+        const long bc = bcol < 0 ? 0 : bcol;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) xb[c] = gld(pp->XB + bc * DIM + c);
+    }
+    const int* rowmap = (EPI == EPI_COV || EPI == EPI_HOSTCOV) ? pp->rowmap : nullptr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = mb + q + 4 * s;
+        double* cp = C + (long)row * ldc + col;
+        double v;
+        if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pp->diag_one) ? 1.0 : 0.0);
+        else if (EPI == EPI_SUB) v = -acc[s];
+        else if (EPI == EPI_COV) {
+            double xa[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xa[c] = gld(pp->XA + (long)row * DIM + c);
+            const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) - acc[s];
+            v = (bcol < 0) ? 0.0 : cv;
+            if (rowmap) {
+                const int op = gldi(rowmap + row);
+                if (op >= 0) gst(pp->C2 + (long)op * ldc + col, v + (op == col ? pp->diag_add : 0.0));
+            }
+        } else {
+            v = (bcol < 0) ? 0.0 : gld(pp->Csrc + (long)row * pp->ldcs + col) - acc[s];
+            if (rowmap) {
+                const int op = gldi(rowmap + row);
+                if (op >= 0) gst(pp->C2 + (long)op * ldc + col, v + (op == col ? pp->diag_add : 0.0));
+            }
+        }
+        gst(cp, v);
+    }
+}
+
+template <int EPI, int DIM, int MODE>
+__global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
     unsigned prob_i, wg_i;
     if (!xcd_problem_tile(G, nprob, prob_i, wg_i)) return;
-    const GemmProb pb = probs[prob_i];
+    const GemmProb* __restrict__ pp = probs + __builtin_amdgcn_readfirstlane(prob_i);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int tn = (pb.N + 31) >> 5, tm = (pb.M + 31) >> 5;
+    const int pM = pp->M, pN = pp->N;
+    const int tn = (pN + 31) >> 5, tm = (pM + 31) >> 5;
     const long tile = (long)wg_i * 4 + wave;
     int mt, nt;
-    if (pb.lower) {
+    if (pp->lower) {
         // lower-triangular products (SYRK, Schur): only the tm(tm+1)/2 tiles on or below the diagonal are
         // enumerated (the host sizes G for them), so no workgroup is launched just to exit
         if (tile >= (long)tm * (tm + 1) / 2) return;
@@ -230,37 +276,45 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         mt = (int)(tile / tn); nt = (int)(tile % tn);
     }
     const int m0 = mt << 5, n0 = nt << 5;
-    const bool mv1 = (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
+    const bool mv1 = (m0 + 16) < pM, nv1 = (n0 + 16) < pN;
 
+    const int* idxB = pp->idxB;
     int br0 = n0 + r, br1 = n0 + 16 + r;
-    if (pb.idxB) {
-        br0 = gldi(pb.idxB + n0 + r);
-        br1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1;
+    if (idxB) {
+        br0 = gldi(idxB + n0 + r);
+        br1 = nv1 ? gldi(idxB + n0 + 16 + r) : -1;
     }
     const bool bz0 = br0 < 0, bz1 = (!nv1) || br1 < 0;
-    d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
     const d4 zero = {0, 0, 0, 0};
+    d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
     // SUB: the C tile is fetched before the products (independent loads in flight together), not element
-    // by element behind the stores of the epilogue
-    d4 cin[4] = {zero, zero, zero, zero};
+    // by element behind the stores of the epilogue, and goes straight into the accumulators (negated; the epilogue
+    // writes -acc = C_in - A B^T)
     if (EPI == EPI_SUB) {
+        const double* Cin = pp->C;
+        const long ldc = pp->ldc;
+        const int zc = pp->zc;
+        d4 cin[4] = {zero, zero, zero, zero};
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const int mb = m0 + (t4 >> 1) * 16, nb = n0 + (t4 & 1) * 16;
             const int col = nb + r;
-            if (mb < pb.M && nb < pb.N && !(pb.zc > 0 && col >= pb.zc)) {
+            if (mb < pM && nb < pN && !(zc > 0 && col >= zc)) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(pb.C + (long)(mb + q + 4 * s4) * pb.ldc + col);
+                for (int s4 = 0; s4 < 4; ++s4) cin[t4][s4] = gld(Cin + (long)(mb + q + 4 * s4) * ldc + col);
             }
         }
-        c00 = -cin[0]; c01 = -cin[1]; c10 = -cin[2]; c11 = -cin[3];     // the epilogue writes -acc = C_in - A B^T
+        c00 = -cin[0]; c01 = -cin[1]; c10 = -cin[2]; c11 = -cin[3];
     }
-    const int nseg = pb.nseg > 0 ? pb.nseg : 1;
+    const int pnseg = pp->nseg;
+    const GemmSeg* segs = pp->segs;
+    const int nseg = pnseg > 0 ? pnseg : 1;
     for (int sg = 0; sg < nseg; ++sg) {
-        const double *Ap = pb.A, *Bp = pb.B;
-        long lda = pb.lda, ldb = pb.ldb;
-        int K = pb.K;
-        if (pb.nseg > 0) { const GemmSeg g = pb.segs[sg]; Ap = g.A; Bp = g.B; lda = g.lda; ldb = g.ldb; K = g.K; }
+        const double *Ap, *Bp;
+        long lda, ldb;
+        int K;
+        if (pnseg > 0) { const GemmSeg* g = segs + sg; Ap = g->A; Bp = g->B; lda = g->lda; ldb = g->ldb; K = g->K; }
+        else { Ap = pp->A; Bp = pp->B; lda = pp->lda; ldb = pp->ldb; K = pp->K; }
         // unconditional global loads one K-step ahead of the MFMAs (rows that do not exist read a valid
         // row and are zeroed by a select): branches around loads force s_waitcnt vmcnt(0) in the loop
         const double* a0p = Ap + (long)(m0 + r) * lda + 4 * q;
@@ -283,46 +337,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmProb* __restrict__ pr
         }
     }
     // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
-    auto emit = [&](d4 acc, int mb, int nb, int bcol, int ti) {
-        const int col = nb + r;
-        double xb[DIM];
-        if (EPI == EPI_COV) {
-            const long bc = bcol < 0 ? 0 : bcol;
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) xb[c] = gld(pb.XB + bc * DIM + c);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int row = mb + q + 4 * s;
-            double* cp = pb.C + (long)row * pb.ldc + col;
-            double v;
-            if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
-            else if (EPI == EPI_SUB) v = -acc[s];
-            else if (EPI == EPI_COV) {
-                double xa[DIM];
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) xa[c] = gld(pb.XA + (long)row * DIM + c);
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, xb, kp.circular)) - acc[s];
-                v = (bcol < 0) ? 0.0 : cv;
-                if (pb.rowmap) {
-                    const int op = gldi(pb.rowmap + row);
-                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
-                }
-            } else {
-                v = (bcol < 0) ? 0.0 : gld(pb.Csrc + (long)row * pb.ldcs + col) - acc[s];
-                if (pb.rowmap) {
-                    const int op = gldi(pb.rowmap + row);
-                    if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
-                }
-            }
-            gst(cp, v);
-        }
-    };
-    const int bc0 = pb.idxB ? br0 : n0 + r, bc1 = pb.idxB ? br1 : n0 + 16 + r;
-    emit(c00, m0, n0, bc0, 0);
-    if (nv1) emit(c01, m0, n0 + 16, bc1, 1);
-    if (mv1) emit(c10, m0 + 16, n0, bc0, 2);
-    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
+    const int bc0 = idxB ? br0 : n0 + r, bc1 = idxB ? br1 : n0 + 16 + r;
+    gemm_nt_emit<EPI, DIM, MODE>(pp, kp, c00, m0, n0, bc0, r, q);
+    if (nv1) gemm_nt_emit<EPI, DIM, MODE>(pp, kp, c01, m0, n0 + 16, bc1, r, q);
+    if (mv1) gemm_nt_emit<EPI, DIM, MODE>(pp, kp, c10, m0 + 16, n0, bc0, r, q);
+    if (mv1 && nv1) gemm_nt_emit<EPI, DIM, MODE>(pp, kp, c11, m0 + 16, n0 + 16, bc1, r, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -636,7 +655,7 @@ struct PanelProb {
     int node;           // where to put 2*sum(log diag L)
 };
 
-__global__ __launch_bounds__(256) void k_panel_chol(const PanelProb* __restrict__ probs,
+__global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restrict__ probs,
                                                      double* __restrict__ dnode, int* __restrict__ err) {
     const PanelProb pb = probs[blockIdx.x];
     __shared__ __attribute__((aligned(16))) double sd[16][17];
@@ -809,7 +828,7 @@ struct TrsmNode {
     int cwt;
 };
 
-__global__ __launch_bounds__(256) void k_trsm_rows(const TrsmNode* __restrict__ nodes,
+__global__ __launch_bounds__(256, 2) void k_trsm_rows(const TrsmNode* __restrict__ nodes,
                                                     const int* __restrict__ tile_node,
                                                     const long* __restrict__ tile_row0, long ntiles,
                                                     double* __restrict__ W, long ldw, int c0,

@@ -18,7 +18,7 @@ struct Stamp { unsigned long long t0, t1, r0, r1; };
 
 // NACC independent accumulators per wave; VFMA extra independent v_fma_f64 per MFMA in the same wave (co-issue test)
 template <int NACC, int VFMA>
-__global__ __launch_bounds__(256) void k_mfma(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_mfma(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     d4 acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_mfma(double* out, const double* __restr
 // as k_mfma<4,0> but every MFMA of a round reads a different (A, B) register pair, like a 2x2 register-blocked GEMM tile
 // (a0 b0, a0 b1, a1 b0, a1 b1): with the SAME two source registers in every instruction the pipe issues only every ~98 cycles,
 // with varying sources every ~64-70 - the register-blocked form is the one real kernels have
-__global__ __launch_bounds__(256) void k_mfma_blk(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_mfma_blk(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     d4 c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_mfma_blk(double* out, const double* __r
     if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
 }
 // one accumulator, alternating source registers: the dependent-chain rate of real code
-__global__ __launch_bounds__(256) void k_mfma_dep(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_mfma_dep(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     d4 c = {0, 0, 0, 0};
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_mfma_dep(double* out, const double* __r
     if ((threadIdx.x & 63) == 0) st[gid >> 6] = Stamp{t0, t1, r0, r1};
 }
 // two accumulators, alternating
-__global__ __launch_bounds__(256) void k_mfma_dep2(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_mfma_dep2(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     d4 c = {0, 0, 0, 0}, e = c;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const double a0 = in[gid & 4095], b0 = in[(gid * 7 + 13) & 4095], a1 = in[(gid * 3 + 1) & 4095], b1 = in[(gid * 5 + 2) & 4095];
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_mfma_dep2(double* out, const double* __
 
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction (512 flop), one f64 per lane for A, B and D
 template <int NACC>
-__global__ __launch_bounds__(256) void k_mfma4(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_mfma4(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     double acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_mfma4(double* out, const double* __rest
 }
 
 // VALU only: 16 independent v_fma_f64 chains
-__global__ __launch_bounds__(256) void k_vfma(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(256, 2) void k_vfma(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     double acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = in[(gid + i) & 4095];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_vfma(double* out, const double* __restr
 }
 
 // mixed workgroup: waves 0..3 (one per SIMD) run MFMA only, waves 4..7 run VALU fma only: do the two pipes add up?
-__global__ __launch_bounds__(512) void k_split(double* out, const double* __restrict__ in, int iters, Stamp* st) {
+__global__ __launch_bounds__(512, 2) void k_split(double* out, const double* __restrict__ in, int iters, Stamp* st) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int wave = threadIdx.x >> 6;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
