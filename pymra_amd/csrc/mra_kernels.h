@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__
 //  flight while step k is on the MFMA pipe).  Halves the L1/L2 operand traffic per MFMA of the
 //  direct-load kernel above; same GemmProb, same epilogues.
 // ------------------------------------------------------------------------------------------------
+#ifndef GL_LDS_LD
 #define GL_LDS_LD 18      /* doubles per staged row: 16 + 2 pad -> conflict-free 32-byte fragment reads */
+#endif
 #define GL_PF 2           /* K-steps the global loads run ahead (register sets); even */
 
 template <int EPI, int DIM, int MODE>
@@ -1627,6 +1629,383 @@ __global__ void k_add_identity(const AsmProb* __restrict__ probs) {
     const AsmProb pb = probs[blockIdx.y];
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < pb.cw) pb.F[(long)a * pb.nf + a] += 1.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Fused non-leaf front: assembly + partial Cholesky + Schur complement in ONE launch per level, the front held
+//  in LDS as 16x16 tiles (pyMRA/MRANode.py:434-445, 463, 476-480):
+//      F = [I on the own block] + sum_children Gt_c ;  Lt = chol(F_oo), Zt = F_ao Lt^-T ;  Gt = F_aa - Zt Zt^T
+//  Replaces k_assemble / k_add_identity + k_panel_chol + k_gemm_nt<SUB> (three dependent launches per level, each
+//  a few tiles of work behind a full launch + global round trips): what bounds the upper levels of the tree is the
+//  length of that dependent chain, not arithmetic.
+//  FULL  : every lower tile of the front fits in LDS (nt (nt+1)/2 + cwt tiles): assemble -> factor -> Schur in LDS, one
+//          coalesced write of the finished front.
+//  PANEL : only the cwt panel columns fit: the front is read from global memory (built by the parent SYRK or by
+//          k_assemble), the Schur update is applied to the trailing tiles in global memory.
+//  Tiles are stored with a row stride of 18 doubles (32-byte fragment reads without bank conflicts); the product idiom is
+//  the vec layout of k_trsm_rows2: with a = rows pi(r) of tile P and b = rows r of tile Q (32 bytes per lane each),
+//  the accumulator is tile (Q P^T) in vec layout again.
+// ------------------------------------------------------------------------------------------------
+#define FT_LD 18
+#define FT_SZ (16 * FT_LD)
+struct FrontProb {
+    double* F;          // nf x nf, row-major, lower part
+    double* invd;       // cwt inverted diagonal blocks (256 doubles each) for the predictive pass
+    int nf;
+    int cwt;            // panel column tiles (own block)
+    int node;
+    int child0, nchild; // children's Schur blocks in the AsmChild array (FULL with assembly)
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(512, 1) void k_front(const FrontProb* __restrict__ probs, const AsmChild* __restrict__ kids,
+                                                   double* __restrict__ dnode, int* __restrict__ err, int do_assemble, int add_identity) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FrontProb* __restrict__ pp = probs + blockIdx.x;
+    double* const F = pp->F;
+    const int nf = pp->nf, cwt = pp->cwt, nt = nf >> 4, cw = cwt << 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int nwave = blockDim.x >> 6;
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    // tile (i, j), j <= i: FULL keeps the whole lower triangle, PANEL the first cwt column tiles
+    auto tix = [&](int i, int j) -> int { return FULL ? (i * (i + 1) / 2 + j) : (j * nt - j * (j - 1) / 2 + (i - j)); };
+    const int n_lds_tiles = FULL ? nt * (nt + 1) / 2 : cwt * nt - cwt * (cwt - 1) / 2;
+    double* const inv = lds + (long)n_lds_tiles * FT_SZ;            // cwt inverted diagonal blocks
+    // ---- A. bring the front in.  16-byte chunks enumerated row by row over the lower trapezoid (tile row block i holds
+    // 16 rows of 8 (i+1) chunks; PANEL: at most cwt column tiles), so consecutive lanes read consecutive chunks of one
+    // front row; FA_G chunks (x up to four children) of every thread are in flight together - a plain load -> add ->
+    // ds_write loop pays one L2 round trip per chunk, which was most of this kernel's run time.
+    {
+        constexpr int FA_G = 4;
+        const int wmax = FULL ? nt : cwt;                     // column tiles kept per row block, at most
+        int nchunk = 0;
+        for (int i = 0; i < nt; ++i) nchunk += 128 * min(i + 1, wmax);
+        const int nchild = (FULL && do_assemble) ? pp->nchild : 0;
+        const AsmChild* kd = kids + pp->child0;
+        for (int e0 = threadIdx.x; e0 < nchunk; e0 += FA_G * (int)blockDim.x) {
+            d2 v[FA_G];
+            int dst[FA_G];
+            long off[FA_G];
+            int grow[FA_G], gcol[FA_G];
+            bool diag0[FA_G], diag1[FA_G];
+#pragma unroll
+            for (int g = 0; g < FA_G; ++g) {
+                int e = e0 + g * (int)blockDim.x;
+                e = e < nchunk ? e : nchunk - 1;
+                int i = 0, base = 0;
+                while (i + 1 < nt && e >= base + 128 * min(i + 1, wmax)) { base += 128 * min(i + 1, wmax); ++i; }
+                const int w8 = 8 * min(i + 1, wmax), rem = e - base;
+                const int row = rem / w8, cc = rem - row * w8, j = cc >> 3, c2 = (cc & 7) << 1;
+                const int gr = i * 16 + row, gc = j * 16 + c2;
+                off[g] = (long)gr * nf + gc;
+                grow[g] = gr; gcol[g] = gc;
+                dst[g] = tix(i, j) * FT_SZ + row * FT_LD + c2;
+                const bool idn = add_identity && i == j && gr < cw;
+                diag0[g] = idn && row == c2;
+                diag1[g] = idn && row == c2 + 1;
+                v[g] = d2{0.0, 0.0};
+            }
+            if (FULL && do_assemble) {
+                for (int c0 = 0; c0 < nchild; c0 += 4) {
+                    d2 t[FA_G][4];
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const int cc = (c0 + ch < nchild) ? c0 + ch : c0;
+                        const double* G = kd[cc].G;
+                        const long ldc = kd[cc].ld;              // a child's Schur block sits inside the child's own (larger) front
+#pragma unroll
+                        for (int g = 0; g < FA_G; ++g) t[g][ch] = gld2(G + (long)grow[g] * ldc + gcol[g]);
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        if (c0 + ch < nchild) {
+#pragma unroll
+                            for (int g = 0; g < FA_G; ++g) v[g] += t[g][ch];
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < FA_G; ++g) v[g] = gld2(F + off[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < FA_G; ++g) {
+                if (e0 + g * (int)blockDim.x < nchunk) {
+                    d2 x = v[g];
+                    if (diag0[g]) x[0] += 1.0;
+                    if (diag1[g]) x[1] += 1.0;
+                    *(d2*)(lds + dst[g]) = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- B. partial Cholesky of the cwt panel columns (left-looking over the panel)
+    double logacc = 0.0;
+    for (int jb = 0; jb < cwt; ++jb) {
+        if (jb > 0) {
+            for (int ib = jb + wave; ib < nt; ib += nwave) {
+                d4 u0 = zero, u1 = zero;
+                for (int kb = 0; kb < jb; ++kb) {
+                    const d4 a = *(const d4*)(lds + (long)tix(jb, kb) * FT_SZ + prow * FT_LD + 4 * q);
+                    const d4 b = *(const d4*)(lds + (long)tix(ib, kb) * FT_SZ + r * FT_LD + 4 * q);
+                    u0 = mfma16(a[0], b[0], u0); u1 = mfma16(a[1], b[1], u1);
+                    u0 = mfma16(a[2], b[2], u0); u1 = mfma16(a[3], b[3], u1);
+                }
+                d4* tp = (d4*)(lds + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
+                *tp = *tp - (u0 + u1);
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            double a[16], m[16];
+            double* dt = lds + (long)tix(jb, jb) * FT_SZ;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
+            bool bad = false;
+            logacc += chol16_inv(a, m, r, bad, nullptr);
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
+                    *(d2*)(inv + jb * FT_SZ + lane * FT_LD + k) = d2{m[k], m[k + 1]};
+                    gst2(pp->invd + (long)jb * 256 + lane * 16 + k, d2{m[k], m[k + 1]});
+                }
+                if (bad && lane == 0) atomicMax(err, pp->node + 1);
+            }
+        }
+        __syncthreads();
+        {
+            const d4 ia = *(const d4*)(inv + jb * FT_SZ + prow * FT_LD + 4 * q);
+            for (int ib = jb + 1 + wave; ib < nt; ib += nwave) {
+                d4* tp = (d4*)(lds + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
+                const d4 b = *tp;
+                d4 x0 = mfma16(ia[0], b[0], zero), x1 = mfma16(ia[1], b[1], zero);
+                x0 = mfma16(ia[2], b[2], x0); x1 = mfma16(ia[3], b[3], x1);
+                *tp = x0 + x1;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- C. Schur complement of the trailing block, D. write back
+    const int ntr = nt - cwt;
+    const int ntrail = ntr * (ntr + 1) / 2;
+    auto trail_ij = [&](int t, int& i, int& j) {
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+        i = cwt + ii; j = cwt + (t - ii * (ii + 1) / 2);
+    };
+    d4 tnext = zero;
+    if (!FULL && wave < ntrail) {                  // PANEL: the trailing tile comes from global memory, one tile ahead
+        int i, j;
+        trail_ij(wave, i, j);
+        tnext = gld4(F + (long)(i * 16 + r) * nf + j * 16 + 4 * q);
+    }
+    for (int t = wave; t < ntrail; t += nwave) {
+        int i, j;
+        trail_ij(t, i, j);
+        d4 tcur = tnext;
+        if (!FULL) {
+            int i2, j2;
+            trail_ij(t + nwave < ntrail ? t + nwave : t, i2, j2);
+            tnext = gld4(F + (long)(i2 * 16 + r) * nf + j2 * 16 + 4 * q);
+        } else {
+            tcur = *(const d4*)(lds + (long)tix(i, j) * FT_SZ + r * FT_LD + 4 * q);
+        }
+        d4 u0 = zero, u1 = zero;
+        for (int kb = 0; kb < cwt; ++kb) {
+            const d4 a = *(const d4*)(lds + (long)tix(j, kb) * FT_SZ + prow * FT_LD + 4 * q);
+            const d4 b = *(const d4*)(lds + (long)tix(i, kb) * FT_SZ + r * FT_LD + 4 * q);
+            u0 = mfma16(a[0], b[0], u0); u1 = mfma16(a[1], b[1], u1);
+            u0 = mfma16(a[2], b[2], u0); u1 = mfma16(a[3], b[3], u1);
+        }
+        gst4(F + (long)(i * 16 + r) * nf + j * 16 + 4 * q, tcur - (u0 + u1));
+    }
+    // panel columns: Lt and Zt
+    for (int t = wave; t < cwt * nt - cwt * (cwt - 1) / 2; t += nwave) {
+        int j = 0, base = 0;
+        while (j + 1 < cwt && t >= base + (nt - j)) { base += nt - j; ++j; }
+        const int i = j + (t - base);
+        gst4(F + (long)(i * 16 + r) * nf + j * 16 + 4 * q, *(const d4*)(lds + (long)tix(i, j) * FT_SZ + r * FT_LD + 4 * q));
+    }
+    if (threadIdx.x == 0) dnode[pp->node] = 2.0 * logacc;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Parents of the leaves: front assembly from the children's Ut blocks AND its factorisation in one launch
+//      F = I_own + sum_c Ut_c Ut_c^T  (MRANode.py:434-440 with the leaves in observation space)  ->  Lt, Zt, Gt as k_front
+//  One workgroup per node.  The K dimension (the children's observations, 16 at a time) streams through a
+//  double-buffered LDS stage shared by the 8 waves; every wave accumulates up to NACC of the node's nt(nt+1)/2 lower
+//  tiles in registers (48 MFMAs per wave and barrier at C3).  The front never makes the HBM round trip between a
+//  SYRK kernel and a factorisation kernel (2 x 177 MB at C3), and the operand fragments come from LDS instead of L2.
+//  Panel tiles go through LDS for the partial Cholesky (as k_front), the trailing tiles take their Schur update in
+//  registers and are written once.
+// ------------------------------------------------------------------------------------------------
+#define PF_LD 20          /* doubles per staged row of 16 k */
+template <int NACC>
+__global__ __launch_bounds__(512, 1) void k_parent_front(const FrontProb* __restrict__ probs, const GemmSeg* __restrict__ segs_all,
+                                                          double* __restrict__ dnode, int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FrontProb* __restrict__ pp = probs + blockIdx.x;
+    double* const F = pp->F;
+    const int nf = pp->nf, cwt = pp->cwt, nt = nf >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    const int ntiles = nt * (nt + 1) / 2;
+    const int npanel = cwt * nt - cwt * (cwt - 1) / 2;
+    // LDS: two staging buffers of nf rows x PF_LD, then the panel tiles (k_front's PANEL layout) and the inverted diagonal blocks
+    double* const stage0 = lds;
+    double* const stage1 = lds + (long)nf * PF_LD;
+    double* const pan = lds + 2L * nf * PF_LD;
+    double* const inv = pan + (long)npanel * FT_SZ;
+    auto tix = [&](int i, int j) -> int { return j * nt - j * (j - 1) / 2 + (i - j); };
+    // this wave's tiles: t = wave + 8 n, row-major over the lower triangle (t = i (i+1)/2 + j)
+    int ti[NACC], tj[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        const int t = wave + 8 * n;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        ti[n] = i; tj[n] = t - i * (i + 1) / 2;
+    }
+    d4 acc[NACC];
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[n] = zero;
+    // ---- K loop over the children's observation columns
+    const GemmSeg* segs = segs_all + pp->child0;
+    const int nseg = pp->nchild;
+    // staging role: 32-byte chunk (row, 4 columns) of the nf x 16 slab; nf * 4 chunks, up to two per thread
+    const int c0 = threadIdx.x, c1 = threadIdx.x + 512;
+    const int nch = nf * 4;
+    const int row0 = (c0 < nch ? c0 : 0) >> 2, col0 = (c0 & 3) << 2;
+    const int row1 = (c1 < nch ? c1 : 0) >> 2, col1 = (c1 & 3) << 2;
+    int sg = 0, k0 = 0;
+    while (sg < nseg && segs[sg].K == 0) ++sg;
+    d4 s0 = zero, s1 = zero;
+    if (sg < nseg) {
+        const double* A = segs[sg].A; const long lda = segs[sg].lda;
+        s0 = gld4(A + (long)row0 * lda + col0);
+        s1 = gld4(A + (long)row1 * lda + col1);
+    }
+    int cur = 0;
+    if (sg < nseg) {
+        if (c0 < nch) *(d4*)(stage0 + row0 * PF_LD + col0) = s0;
+        if (c1 < nch) *(d4*)(stage0 + row1 * PF_LD + col1) = s1;
+    }
+    __syncthreads();
+    while (sg < nseg) {
+        // next chunk (if any) into registers while this one is on the MFMA pipe
+        int sg2 = sg, k2 = k0 + 16;
+        if (k2 >= segs[sg2].K) { k2 = 0; ++sg2; while (sg2 < nseg && segs[sg2].K == 0) ++sg2; }
+        const bool more = sg2 < nseg;
+        {
+            const int sl = more ? sg2 : sg;
+            const int kl = more ? k2 : k0;
+            const double* A = segs[sl].A; const long lda = segs[sl].lda;
+            s0 = gld4(A + (long)row0 * lda + kl + col0);
+            s1 = gld4(A + (long)row1 * lda + kl + col1);
+        }
+        const double* st = cur ? stage1 : stage0;
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+            if (wave + 8 * n < ntiles) {
+                const d4 a = *(const d4*)(st + (tj[n] * 16 + prow) * PF_LD + 4 * q);
+                const d4 b = *(const d4*)(st + (ti[n] * 16 + r) * PF_LD + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[n] = mfma16(a[j], b[j], acc[n]);
+            }
+        }
+        if (more) {
+            double* sn = cur ? stage0 : stage1;
+            if (c0 < nch) *(d4*)(sn + row0 * PF_LD + col0) = s0;
+            if (c1 < nch) *(d4*)(sn + row1 * PF_LD + col1) = s1;
+        }
+        __syncthreads();
+        cur ^= 1; sg = sg2; k0 = k2;
+    }
+    // ---- identity on the own block, panel tiles to LDS
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        if (wave + 8 * n < ntiles) {
+            if (ti[n] == tj[n] && ti[n] < cwt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[n][j] += (r == 4 * q + j) ? 1.0 : 0.0;
+            }
+            if (tj[n] < cwt) *(d4*)(pan + (long)tix(ti[n], tj[n]) * FT_SZ + r * FT_LD + 4 * q) = acc[n];
+        }
+    }
+    __syncthreads();
+    // ---- partial Cholesky of the panel (k_front, phase B); the diagonal blocks go to the last wave (fewest tiles in registers)
+    double logacc = 0.0;
+    const int nwave = 8;
+    for (int jb = 0; jb < cwt; ++jb) {
+        if (jb > 0) {
+            for (int ib = jb + wave; ib < nt; ib += nwave) {
+                d4 u0 = zero, u1 = zero;
+                for (int kb = 0; kb < jb; ++kb) {
+                    const d4 a = *(const d4*)(pan + (long)tix(jb, kb) * FT_SZ + prow * FT_LD + 4 * q);
+                    const d4 b = *(const d4*)(pan + (long)tix(ib, kb) * FT_SZ + r * FT_LD + 4 * q);
+                    u0 = mfma16(a[0], b[0], u0); u1 = mfma16(a[1], b[1], u1);
+                    u0 = mfma16(a[2], b[2], u0); u1 = mfma16(a[3], b[3], u1);
+                }
+                d4* tp = (d4*)(pan + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
+                *tp = *tp - (u0 + u1);
+            }
+            __syncthreads();
+        }
+        if (wave == nwave - 1) {
+            double a[16], m[16];
+            double* dt = pan + (long)tix(jb, jb) * FT_SZ;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
+            bool bad = false;
+            logacc += chol16_inv(a, m, r, bad, nullptr);
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
+                    *(d2*)(inv + jb * FT_SZ + lane * FT_LD + k) = d2{m[k], m[k + 1]};
+                    gst2(pp->invd + (long)jb * 256 + lane * 16 + k, d2{m[k], m[k + 1]});
+                }
+                if (bad && lane == 0) atomicMax(err, pp->node + 1);
+            }
+        }
+        __syncthreads();
+        {
+            const d4 ia = *(const d4*)(inv + jb * FT_SZ + prow * FT_LD + 4 * q);
+            for (int ib = jb + 1 + wave; ib < nt; ib += nwave) {
+                d4* tp = (d4*)(pan + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
+                const d4 b = *tp;
+                d4 x0 = mfma16(ia[0], b[0], zero), x1 = mfma16(ia[1], b[1], zero);
+                x0 = mfma16(ia[2], b[2], x0); x1 = mfma16(ia[3], b[3], x1);
+                *tp = x0 + x1;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- Schur update of the trailing tiles in registers, everything out
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+        if (wave + 8 * n < ntiles) {
+            const int i = ti[n], j = tj[n];
+            double* gp = F + (long)(i * 16 + r) * nf + j * 16 + 4 * q;
+            if (j < cwt) {
+                gst4(gp, *(const d4*)(pan + (long)tix(i, j) * FT_SZ + r * FT_LD + 4 * q));
+            } else {
+                d4 u0 = zero, u1 = zero;
+                for (int kb = 0; kb < cwt; ++kb) {
+                    const d4 a = *(const d4*)(pan + (long)tix(j, kb) * FT_SZ + prow * FT_LD + 4 * q);
+                    const d4 b = *(const d4*)(pan + (long)tix(i, kb) * FT_SZ + r * FT_LD + 4 * q);
+                    u0 = mfma16(a[0], b[0], u0); u1 = mfma16(a[1], b[1], u1);
+                    u0 = mfma16(a[2], b[2], u0); u1 = mfma16(a[3], b[3], u1);
+                }
+                gst4(gp, acc[n] - (u0 + u1));
+            }
+        }
+    }
+    if (threadIdx.x == 64 * (nwave - 1)) dnode[pp->node] = 2.0 * logacc;
 }
 
 // mean = -W[:, Ka]

@@ -135,6 +135,9 @@ struct LevelData {
     DevVec<long> tile_row0;
     long ntiles = 0;
     DevVec<AsmProb> gAsm;
+    DevVec<FrontProb> gFront;
+    int front_mode = 0;               // 0: separate launches, 1: k_front<PANEL>, 2: k_front<FULL> (whole front in LDS)
+    size_t front_lds = 0;
     double fl_resid = 0, fl_pchol = 0, fl_trsm = 0, fl_fchol = 0, fl_schur = 0, fl_update = 0;
 };
 
@@ -188,6 +191,9 @@ struct mra_plan {
     int trsm_small_nt = 0, trsm_small_tiles_full = 0, trsm_small_tiles_lik = 0;
     DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
     DevVec<GemmSeg> parentSegs;
+    DevVec<FrontProb> gParentFront;      // the same nodes for k_parent_front (SYRK + factorisation in one launch)
+    int parent_front_nacc = 0;           // 0: not available (front too large for the register-resident SYRK)
+    size_t parent_front_lds = 0;
     bool parent_syrk = false, direct_parent = false;
     bool shape_regular = false;          // every leaf sits on the last level (all other levels hold non-leaf nodes only)
     std::vector<AsmChild> hKids;         // host copies: the leaves' Gt blocks are allocated only when something needs them
@@ -199,7 +205,7 @@ struct mra_plan {
     int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
     // fused ("regular tree") path
-    bool regular = false, use_fused = true, gemm_lds = true;
+    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true;
     int NL = 0, CWT = 0;
     struct FusedLevel {
         DevVec<double> kx, Wk;
@@ -363,6 +369,7 @@ static void build_static(mra_plan* pl) {
         std::vector<TrsmNode> tpr(nn), tpo(nn);
         std::vector<Trsm2Prob> t2pr(nn), t2po(nn);
         std::vector<AsmProb> as(nn);
+        std::vector<FrontProb> fr(nn);
         std::vector<int> tnode;
         std::vector<long> trow;
         const int Kanc = pl->Ka - lv.a0;
@@ -424,6 +431,15 @@ static void build_static(mra_plan* pl) {
                 kids.push_back(k);
             }
             as[s] = a;
+            fr[s] = FrontProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt, i, a.child0, a.nchild};
+        }
+        {
+            const long nt = lv.nf / 16;
+            const size_t full = (size_t)(nt * (nt + 1) / 2 + lv.cwt) * FT_SZ * sizeof(double);
+            const size_t panel = (size_t)(lv.cwt * nt - lv.cwt * (lv.cwt - 1) / 2 + lv.cwt) * FT_SZ * sizeof(double);
+            lv.front_mode = full <= 160 * 1024 ? 2 : (panel <= 160 * 1024 ? 1 : 0);
+            lv.front_lds = lv.front_mode == 2 ? full : panel;
+            lv.gFront.upload(fr);
         }
         lv.hResid = resid;
         lv.gResid.upload(resid); lv.gSchur.upload(schur); lv.gUpdate.upload(upd); lv.gKinv.upload(kinv);
@@ -667,6 +683,18 @@ static void build_leaf(mra_plan* pl, const double* y) {
         }
         pl->gParentSyrk.upload(ps);
         pl->parent_syrk = true;
+        {
+            std::vector<FrontProb> pf(lv.nodes.size());
+            for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx)
+                pf[sidx] = FrontProb{lv.F.p + sidx * (size_t)lv.nf * lv.nf, lv.invF.p + sidx * (size_t)lv.cwt * 256, lv.nf, lv.cwt,
+                                     lv.nodes[sidx], (int)where[sidx].first, where[sidx].second};
+            pl->gParentFront.upload(pf);
+            const long nt = lv.nf / 16, ntiles = nt * (nt + 1) / 2;
+            const long npanel = lv.cwt * nt - lv.cwt * (lv.cwt - 1) / 2;
+            pl->parent_front_lds = (size_t)(2 * lv.nf * PF_LD + (npanel + lv.cwt) * FT_SZ) * sizeof(double);
+            pl->parent_front_nacc = ntiles <= 16 ? 2 : (ntiles <= 32 ? 4 : (ntiles <= 64 ? 8 : (ntiles <= 96 ? 12 : 0)));
+            if (pl->parent_front_lds > 160 * 1024) pl->parent_front_nacc = 0;
+        }
     }
     pl->hLeafResid = gr; pl->leaf_nobs_host = nobs;
     pl->gLeafResidLik.upload(grl);
@@ -899,6 +927,29 @@ static void run_predict_fused(mra_plan* pl) {
 // (each hipEventRecord between dependent launches leaves a ~6 us gap on the stream)
 static void phase_mark(mra_plan* pl, int k) { if (k == 0 || k == 5 || pl->ktiming) hipEventRecord(pl->ev[k], pl->stream); }
 
+// factorise the fronts of level m (already assembled in global memory unless do_assemble): fused kernel when the
+// front (or at least its panel) fits in LDS, else panel Cholesky + Schur GEMM as separate launches
+static bool run_front_fused(mra_plan* pl, int m, bool do_assemble, bool add_identity) {
+    LevelData& lv = pl->lev[m];
+    const size_t nn = lv.nodes.size();
+    if (!nn) return true;
+    if (!pl->use_front_fused || lv.front_mode == 0 || (do_assemble && lv.front_mode != 2)) return false;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)k_front<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_front<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    KTimer kt(pl, KF_FRONT_CHOL, lv.fl_fchol + lv.fl_schur);
+    if (lv.front_mode == 2)
+        hipLaunchKernelGGL(k_front<true>, dim3((unsigned)nn), dim3(512), lv.front_lds, pl->stream, lv.gFront.p, pl->asmKids.p,
+                           pl->dnode.p, pl->errflag.p, do_assemble ? 1 : 0, add_identity ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_front<false>, dim3((unsigned)nn), dim3(512), lv.front_lds, pl->stream, lv.gFront.p, pl->asmKids.p,
+                           pl->dnode.p, pl->errflag.p, 0, add_identity ? 1 : 0);
+    return true;
+}
+
 static void run_front_level(mra_plan* pl, int m) {
     LevelData& lv = pl->lev[m];
     const size_t nn = lv.nodes.size();
@@ -930,13 +981,40 @@ static void finish_run(mra_plan* pl);
 static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
     for (int m = m_from; m >= 0; --m) {
         const bool is_red = (m == pl->reduce_level);
+        bool need_identity = false;          // front sits in global memory without its identity block
+        bool assembled = true;
         if (!(resume && m == m_from)) {
             if (pl->direct_parent && m == pl->NL - 1) {
                 const LevelData& lvp = pl->lev[m];
+                if (pl->use_front_fused && pl->parent_front_nacc > 0) {
+                    // children's Ut -> front -> Lt, Zt, Schur block, all in one launch (the front never visits HBM unfactorised)
+                    static bool attr = false;
+                    if (!attr) {
+                        hipFuncSetAttribute((const void*)k_parent_front<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncSetAttribute((const void*)k_parent_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncSetAttribute((const void*)k_parent_front<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncSetAttribute((const void*)k_parent_front<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        attr = true;
+                    }
+                    KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk + lvp.fl_fchol + lvp.fl_schur);
+                    const dim3 grid((unsigned)lvp.nodes.size());
+                    const size_t lds = pl->parent_front_lds;
+                    switch (pl->parent_front_nacc) {
+                        case 2: hipLaunchKernelGGL(k_parent_front<2>, grid, dim3(512), lds, pl->stream, pl->gParentFront.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p); break;
+                        case 4: hipLaunchKernelGGL(k_parent_front<4>, grid, dim3(512), lds, pl->stream, pl->gParentFront.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p); break;
+                        case 8: hipLaunchKernelGGL(k_parent_front<8>, grid, dim3(512), lds, pl->stream, pl->gParentFront.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p); break;
+                        default: hipLaunchKernelGGL(k_parent_front<12>, grid, dim3(512), lds, pl->stream, pl->gParentFront.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p); break;
+                    }
+                    continue;
+                }
                 KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk);
                 launch_gemm<EPI_SET>(pl, pl->gParentSyrk.p, lvp.nodes.size(), lvp.nf, lvp.nf, false, true);
-            } else
-            run_assemble_level(pl, m, !is_red);
+            } else if (is_red) {
+                run_assemble_level(pl, m, false);
+                need_identity = true;
+            } else {
+                assembled = false;               // the fused front kernel assembles in LDS when the whole front fits
+            }
             if (is_red) {
                 // the reduce level's fronts are summed over ranks WITHOUT their identity blocks; the
                 // 16-double tail of the buffer carries the rank-local log-det sum of everything below
@@ -955,8 +1033,15 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 if (pl->allreduce(lv.F.p, lv.F.p, lv.F.n, ncclDouble, ncclSum, pl->comm, pl->stream) != ncclSuccess)
                     throw MraError(MRA_ERR_COMM, "ncclAllReduce failed");
             }
+        } else {
+            need_identity = is_red;
         }
-        if (is_red) run_add_identity(pl, m);
+        if (!assembled) {
+            if (run_front_fused(pl, m, true, true)) continue;
+            run_assemble_level(pl, m, true);
+        }
+        if (run_front_fused(pl, m, false, need_identity)) continue;
+        if (need_identity) run_add_identity(pl, m);
         run_front_level(pl, m);
     }
     phase_mark(pl, 3);
@@ -1509,6 +1594,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
     if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
+    if (option == 4) { pl->use_front_fused = value != 0; return MRA_OK; }
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }
 

@@ -21,7 +21,10 @@ __global__ void k_probe(int* out) {
         }
 }
 
-#define LD 20      /* doubles per staged row of 16 k: 160 B -> 32-byte fragment reads of 8 rows hit 8 disjoint bank groups */
+#ifndef LD
+#define LD 20
+#endif
+// LD: doubles per staged row of 16 k: 160 B -> 32-byte fragment reads of 8 rows hit 8 disjoint bank groups */
 // 16x16x4 form: the inner loop of k_gemm_nt_lds (2 A + 2 B fragment reads of 32 B, 16 MFMAs per 16 k)
 __global__ __launch_bounds__(256, 2) void k_tile16(double* out, const double* __restrict__ in, int ksteps, int reps) {
     __shared__ __attribute__((aligned(16))) double sA[64 * LD], sB[64 * LD];
@@ -89,6 +92,74 @@ __global__ __launch_bounds__(256, 2) void k_tile4(double* out, const double* __r
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// ---- what does each ingredient of the LDS-GEMM K-step cost?  Same 64x64 workgroup tile / 32x32 wave tile as k_tile16, plus
+//   STAGE 1: one __syncthreads per K-step (double-buffered LDS image, nothing written)
+//   STAGE 2: + every thread writes its 32-byte chunk of A and of B into the other buffer each step (ds_write)
+//   STAGE 3: + those chunks come from global memory (an L2-resident panel), loaded two steps ahead
+//   BK: K-values per barrier (16: one 16-MFMA group per barrier as in k_gemm_nt_lds; 32: two groups)
+template <int STAGE, int BK>
+__global__ __launch_bounds__(256, 4) void k_tile16s(double* out, const double* __restrict__ in, const double* __restrict__ panel, int ksteps, int reps) {
+    constexpr int NG = BK / 16;
+    __shared__ __attribute__((aligned(16))) double sA[2][NG][64 * LD], sB[2][NG][64 * LD];
+    for (int e = threadIdx.x; e < 2 * NG * 64 * LD; e += 256) { (&sA[0][0][0])[e] = in[e & 4095]; (&sB[0][0][0])[e] = in[(e * 7 + 3) & 4095]; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+    const d4 zero = {0, 0, 0, 0};
+    d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
+    const int a0o = (wr0 + r) * LD + 4 * q, b0o = (wc0 + r) * LD + 4 * q;
+    const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
+    // global source: row (block & 7, srow) of a [rows][K] panel; 8 x 64 rows x 1024 k x 8 B = 4 MiB per operand: L2-resident, re-read
+    const double* ap = panel + ((size_t)(blockIdx.x & 7) * 64 + srow) * 4096 + sch;
+    const double* bp = ap + 256 * 64 * 4096;
+    d4 ra[2][NG], rb[2][NG];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { ra[i][g] = zero; rb[i][g] = zero; }
+    if (STAGE >= 3) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { ra[i][g] = *(const d4*)(ap + (i * NG + g) * 16); rb[i][g] = *(const d4*)(bp + (i * NG + g) * 16); }
+    }
+    const int nst = ksteps * 16 / BK;
+    for (int rep = 0; rep < reps; ++rep)
+        for (int ks0 = 0; ks0 < nst; ks0 += 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ks = ks0 + i, cur = i & 1;
+                if (STAGE >= 3) {
+                    const int ko = ((ks + 2) * BK) & 1023;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) { ra[i][g] = *(const d4*)(ap + ko + g * 16); rb[i][g] = *(const d4*)(bp + ko + g * 16); }
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const d4 a0 = *(const d4*)(&sA[cur][g][a0o]), a1 = *(const d4*)(&sA[cur][g][a0o + 16 * LD]);
+                    const d4 b0 = *(const d4*)(&sB[cur][g][b0o]), b1 = *(const d4*)(&sB[cur][g][b0o + 16 * LD]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], b0[j], c00, 0, 0, 0);
+                        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], b1[j], c01, 0, 0, 0);
+                        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b0[j], c10, 0, 0, 0);
+                        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b1[j], c11, 0, 0, 0);
+                    }
+                }
+                if (STAGE >= 2) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        *(d4*)(&sA[cur ^ 1][g][srow * LD + sch]) = ra[(i + 1) & 1][g];
+                        *(d4*)(&sB[cur ^ 1][g][srow * LD + sch]) = rb[(i + 1) & 1][g];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    const d4 s = c00 + c01 + c10 + c11;
+    out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 int main(int argc, char** argv) {
     int* dprobe; hipMalloc(&dprobe, 4096 * sizeof(int));
     hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dprobe);
@@ -122,6 +193,30 @@ int main(int argc, char** argv) {
             hipEventElapsedTime(&ms, e0, e1);
             const double fl = (double)blocks * 4 * reps * ksteps * 16 * 2048.0;
             printf("%s LDS-fed 32x32 wave tile, %d workgroup(s)/CU: %.2f TFLOP/s (%.3f ms)\n", which ? "4x4x4_4b " : "16x16x4  ", wpc, fl / ms / 1e9, ms);
+        }
+    }
+    {
+        double* panel; hipMalloc(&panel, (size_t)2 * 256 * 64 * 4096 * 8);          // 1 GiB... 2 x 64 MiB x 8 B: per block 2 MiB of A and B rows
+        hipMemset(panel, 0, (size_t)2 * 256 * 64 * 4096 * 8);
+        auto run = [&](auto kern, const char* name, int wpc) {
+            const int blocks = 256 * wpc;
+            float ms;
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, d, din, panel, ksteps, reps);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            hipEventElapsedTime(&ms, e0, e1);
+            const double fl = (double)blocks * 4 * reps * ksteps * 16 * 2048.0;
+            printf("%-70s %d workgroups/CU: %6.2f TFLOP/s\n", name, wpc, fl / ms / 1e9);
+        };
+        for (int wpc = 2; wpc <= 4; wpc += 2) {
+            run(k_tile16s<1, 16>, "tile16 + barrier per 16 k", wpc);
+            run(k_tile16s<2, 16>, "tile16 + barrier + ds_write staging per 16 k", wpc);
+            run(k_tile16s<3, 16>, "tile16 + barrier + ds_write + global loads 2 steps ahead, per 16 k", wpc);
+            run(k_tile16s<1, 32>, "tile16 + barrier per 32 k", wpc);
+            run(k_tile16s<2, 32>, "tile16 + barrier + ds_write staging per 32 k", wpc);
+            run(k_tile16s<3, 32>, "tile16 + barrier + ds_write + global loads 2 steps ahead, per 32 k", wpc);
         }
     }
     return 0;
