@@ -43,6 +43,8 @@ __device__ __forceinline__ void gst4(double* p, d4 v) { *(d4 MRA_AS1*)p = v; }
 
 
 #define MRA_YB 16
+#define FT_LD 18                /* row stride (doubles) of a 16x16 tile held in LDS by the front / knot-chain kernels */
+#define FT_SZ (16 * FT_LD)
 
 // row permutation of the "vec" tile layout (see k_trsm_rows2)
 __device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
@@ -1052,6 +1054,7 @@ struct CascadeArgs {
     double* Lp_out;           // [node][cw][cw]
     double* invd_out;         // [node][cwt][256]
     int* err;
+    int dbg;                  // what-if timing switches (results are wrong when set): 1 no Ut scatter, 2 no W stores, 4 constant instead of kernel evaluation
     int node_base;            // KNOT: node number of slot 0 of the level being factorised (error reports name node + 1)
 };
 
@@ -1090,13 +1093,21 @@ __device__ __forceinline__ void cascade_stage_level(const CascadeArgs& ar, int m
 }
 
 template <int CWT, int NLMAX, int DIM, int MODE>
+__device__ __forceinline__ void cascade_compute_level_kx(const double* __restrict__ kx, const KernelParams& kp, int m,
+                                                         const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
+                                                         const double* xr, int prow, int q, int dbg);
+template <int CWT, int NLMAX, int DIM, int MODE>
 __device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, const KernelParams& kp, int m, int slot,
                                                       const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
                                                       const double* xr, int prow, int q) {
-    constexpr int CW = CWT * 16;
+    cascade_compute_level_kx<CWT, NLMAX, DIM, MODE>(ar.lev[m].kx + (long)slot * (CWT * 16) * DIM, kp, m, ldsb, w, xr, prow, q, ar.dbg);
+}
+template <int CWT, int NLMAX, int DIM, int MODE>
+__device__ __forceinline__ void cascade_compute_level_kx(const double* __restrict__ kx, const KernelParams& kp, int m,
+                                                         const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
+                                                         const double* xr, int prow, int q, int dbg) {
     constexpr int NTRI = CWT * (CWT - 1) / 2;
     const d4 zero = {0, 0, 0, 0};
-    const double* kx = ar.lev[m].kx + (long)slot * CW * DIM;
     const int nwk = CWT * m * CWT;
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
@@ -1119,7 +1130,7 @@ __device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, con
 #pragma unroll
             for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular)) - acc[j];
+            for (int j = 0; j < 4; ++j) res[j] = ((dbg & 4) ? kc[j * DIM] * 1e-3 : cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular))) - acc[j];
         }
         d4 upd = zero;
 #pragma unroll
@@ -1193,10 +1204,10 @@ __device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, in
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
         const d4 v = w[m][jb];
-        *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+        if (!(ar.dbg & 2)) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
         ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    if (op >= 0) {
+    if (op >= 0 && !(ar.dbg & 1)) {
         const int lf = ar.tile_leaf[t];
         double* ut = ar.leaf_ut[lf];
         const long nop = ar.leaf_nop[lf];
@@ -1331,6 +1342,176 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             chol_wave_body(ar.Lp_out + (long)slotk * CW * CW, CW, CWT, ar.invd_out + (long)slotk * CWT * 256, s_sd, s_si, lane, bad);
             if (bad && lane == 0) atomicMax(ar.err, ar.node_base + slotk + 1);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Knot pass of ALL levels in one launch.  The per-level launches of the knot mode above form a chain of NL dependent
+//  kernels, each a few microseconds of work behind global round trips (stage the ancestors' operands, write Wk,
+//  read it back for kInv, factorise in global memory): 0.22 ms at C3 however few nodes a level has - a fixed cost that
+//  does not shrink when the tree is sharded.  Here one workgroup per node of the LAST non-leaf level walks down its own
+//  ancestor chain, level by level, recomputing every ancestor redundantly (bit-identical in every workgroup) with the
+//  operand images kept in LDS from one level to the next; nothing is exchanged between workgroups and nothing is read
+//  back from global memory.  Results go to the level arrays from the first workgroup below each node ("owner").
+//  LDS: images of levels 0 .. NL-2 in the row cascade's layout (cascade_level_off), then NT2 + CWT padded tiles of
+//  factorisation scratch.
+// ------------------------------------------------------------------------------------------------
+struct KnotChainArgs {
+    CascadeLevel lev[8];          // level arrays: kx (in), Wk / L / invd (out)
+    const int* kt_rows[8];        // [node slot][CWT][16] knot rows, -1 = phantom
+    const int* owner[8];          // [node slot] -> workgroup (slot on the last non-leaf level) that writes the node's results
+    const int* chain;             // [workgroup][8] node slot per level
+    const double* X;
+    int nl;
+    int node_base[8];             // node number of slot 0 per level (error reports)
+    int* err;
+};
+
+template <int CWT, int NLMAX, int DIM, int MODE>
+__global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelParams kp) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CW = CWT * 16;
+    constexpr int NTRI = CWT * (CWT - 1) / 2;
+    constexpr int NT2 = CWT * (CWT + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int nwave = blockDim.x >> 6;
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    const int* chain = ka.chain + (long)blockIdx.x * 8;
+    const int nl = ka.nl;
+    double* const fs = lds + (long)cascade_level_off<CWT>(nl - 1) * 256;     // NT2 lower tiles (FT_SZ each), then CWT inverse tiles
+    double* const finv = fs + NT2 * FT_SZ;
+#pragma unroll 1
+    for (int m = 0; m < nl; ++m) {
+        const int slot = chain[m];
+        const bool own = ka.owner[m][slot] == (int)blockIdx.x;
+        const bool last = m == nl - 1;
+        double* const img = lds + (long)cascade_level_off<CWT>(m) * 256;      // image of level m (unused for the last level)
+        const int Kw = m * CW;
+        double* const Wk_g = const_cast<double*>(ka.lev[m].Wk) + (long)slot * CW * Kw;
+        const double* kxn = ka.lev[m].kx + (long)slot * CW * DIM;
+        // ---- 1. knot rows down the levels < m: Wk tiles
+        if (wave < CWT && m > 0) {
+            const int rr = ka.kt_rows[m][((long)slot * CWT + wave) * 16 + r];
+            const bool phantom_row = rr < 0;
+            const long myrow = phantom_row ? 0 : rr;
+            double xr[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xr[c] = ka.X[myrow * DIM + c];
+            d4 w[NLMAX][CWT];
+#pragma unroll
+            for (int k = 0; k < NLMAX; ++k)
+                if (k < m) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE>(ka.lev[k].kx + (long)chain[k] * CW * DIM, kp, k,
+                                                                              lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0);
+#pragma unroll
+            for (int k = 0; k < NLMAX; ++k) {
+                if (k < m) {
+#pragma unroll
+                    for (int kt = 0; kt < CWT; ++kt) {
+                        const d4 v = phantom_row ? zero : w[k][kt];
+                        if (!last) *(d4*)(img + (long)(wave * (m * CWT) + k * CWT + kt) * 256 + r * 16 + 4 * q) = v;
+                        if (own || last) *(d4*)(Wk_g + (long)(wave * 16 + r) * Kw + (k * CWT + kt) * 16 + 4 * q) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2. kInv = kernel(knots, knots) - Wk Wk^T, lower tiles into the factorisation scratch
+        for (int idx = wave; idx < NT2; idx += nwave) {
+            int ib = 0;
+            while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
+            const int jb = idx - ib * (ib + 1) / 2;
+            d4 acc = zero;
+            for (int kk = 0; kk < m * CWT; ++kk) {
+                d4 a, b;
+                if (!last) {
+                    a = *(const d4*)(img + (long)(jb * (m * CWT) + kk) * 256 + prow * 16 + 4 * q);
+                    b = *(const d4*)(img + (long)(ib * (m * CWT) + kk) * 256 + r * 16 + 4 * q);
+                } else {
+                    a = *(const d4*)(Wk_g + (long)(jb * 16 + prow) * Kw + kk * 16 + 4 * q);
+                    b = *(const d4*)(Wk_g + (long)(ib * 16 + r) * Kw + kk * 16 + 4 * q);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
+            }
+            double xi[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) xi[c] = kxn[(long)(ib * 16 + r) * DIM + c];
+            d4 res;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                res[j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xi, kxn + (long)(jb * 16 + 4 * q + j) * DIM, kp.circular)) - acc[j];
+            *(d4*)(fs + (long)idx * FT_SZ + r * FT_LD + 4 * q) = res;
+        }
+        __syncthreads();
+        // ---- 3. Cholesky of the CW x CW block in LDS (left-looking over column tiles, diagonal blocks on wave 0)
+        for (int jb = 0; jb < CWT; ++jb) {
+            if (jb > 0) {
+                for (int ib = jb + wave; ib < CWT; ib += nwave) {
+                    d4 u = zero;
+                    for (int kb = 0; kb < jb; ++kb) {
+                        const d4 a = *(const d4*)(fs + (long)(jb * (jb + 1) / 2 + kb) * FT_SZ + prow * FT_LD + 4 * q);
+                        const d4 b = *(const d4*)(fs + (long)(ib * (ib + 1) / 2 + kb) * FT_SZ + r * FT_LD + 4 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) u = mfma16(a[j], b[j], u);
+                    }
+                    d4* tp = (d4*)(fs + (long)(ib * (ib + 1) / 2 + jb) * FT_SZ + r * FT_LD + 4 * q);
+                    *tp = *tp - u;
+                }
+                __syncthreads();
+            }
+            if (wave == 0) {
+                double a[16], mi[16];
+                double* dt = fs + (long)(jb * (jb + 1) / 2 + jb) * FT_SZ;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
+                bool bad = false;
+                chol16_inv(a, mi, r, bad, nullptr);
+                if (lane < 16) {
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2) {
+                        *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
+                        *(d2*)(finv + jb * FT_SZ + lane * FT_LD + k) = d2{mi[k], mi[k + 1]};
+                    }
+                    if (bad && lane == 0) atomicMax(ka.err, ka.node_base[m] + slot + 1);
+                }
+            }
+            __syncthreads();
+            {
+                const d4 ia = *(const d4*)(finv + jb * FT_SZ + prow * FT_LD + 4 * q);
+                for (int ib = jb + 1 + wave; ib < CWT; ib += nwave) {
+                    d4* tp = (d4*)(fs + (long)(ib * (ib + 1) / 2 + jb) * FT_SZ + r * FT_LD + 4 * q);
+                    const d4 b = *tp;
+                    d4 x = zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x = mfma16(ia[j], b[j], x);
+                    *tp = x;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- 4. factor into the level's image (strictly-lower tiles, inverted diagonal blocks) and, from the owner, into
+        //         the level arrays (row-major CW x CW factor with zeros above the diagonal, CWT inverse blocks)
+        for (int idx = wave; idx < NT2 + CWT; idx += nwave) {
+            if (idx < NT2) {
+                int ib = 0;
+                while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
+                const int jb = idx - ib * (ib + 1) / 2;
+                const d4 v = *(const d4*)(fs + (long)idx * FT_SZ + r * FT_LD + 4 * q);
+                if (!last && ib > jb) *(d4*)(img + (long)(CWT * m * CWT + ib * (ib - 1) / 2 + jb) * 256 + r * 16 + 4 * q) = v;
+                if (own || last) {
+                    double* Lg = const_cast<double*>(ka.lev[m].L) + (long)slot * CW * CW;
+                    *(d4*)(Lg + (long)(ib * 16 + r) * CW + jb * 16 + 4 * q) = v;
+                    if (ib > jb) *(d4*)(Lg + (long)(jb * 16 + r) * CW + ib * 16 + 4 * q) = zero;
+                }
+            } else {
+                const int jb = idx - NT2;
+                const d4 v = *(const d4*)(finv + jb * FT_SZ + r * FT_LD + 4 * q);
+                if (!last) *(d4*)(img + (long)(CWT * m * CWT + NTRI + jb) * 256 + r * 16 + 4 * q) = v;
+                if (own || last) *(d4*)(const_cast<double*>(ka.lev[m].invd) + ((long)slot * CWT + jb) * 256 + r * 16 + 4 * q) = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1646,8 +1827,6 @@ __global__ void k_add_identity(const AsmProb* __restrict__ probs) {
 //  the vec layout of k_trsm_rows2: with a = rows pi(r) of tile P and b = rows r of tile Q (32 bytes per lane each),
 //  the accumulator is tile (Q P^T) in vec layout again.
 // ------------------------------------------------------------------------------------------------
-#define FT_LD 18
-#define FT_SZ (16 * FT_LD)
 struct FrontProb {
     double* F;          // nf x nf, row-major, lower part
     double* invd;       // cwt inverted diagonal blocks (256 doubles each) for the predictive pass

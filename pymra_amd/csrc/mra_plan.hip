@@ -206,6 +206,7 @@ struct mra_plan {
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
     // fused ("regular tree") path
     bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true;
+    int dbg = 0;
     int NL = 0, CWT = 0;
     struct FusedLevel {
         DevVec<double> kx, Wk;
@@ -221,6 +222,13 @@ struct mra_plan {
     long n_ftiles = 0, n_fwg = 0;
     size_t cascade_lds = 0, cascade_lds_all = 0;
     bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
+    bool cascade_group_siblings = false;
+    // knot pass of all levels in one launch (k_knot_chain)
+    bool use_knot_chain = true, knot_chain_ok = false;
+    int kc_levels = 0;                    // levels 0 .. kc_levels-1 go through the chain kernel
+    size_t knot_chain_lds = 0;
+    DevVec<int> kc_chain;                 // [bottom slot][8]
+    std::vector<DevVec<int>> kc_owner;    // per level [slot] -> owning workgroup
     int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels (4 or 8; 4 measured faster)
     DevVec<long> ft_wg0_leaf;
     DevVec<int> ft_wgn_leaf;
@@ -529,13 +537,58 @@ static void build_static(mra_plan* pl) {
                 f.gKinv.upload(gk);
             }
         }
+        {
+            // k_knot_chain: one workgroup per node of the last non-leaf level; owner of an upper node = first workgroup below it
+            // (it recomputes every ancestor in every workgroup, so it only pays while one round of workgroups covers the
+            // level: the chain covers levels 0 .. kc_levels-1, the deepest level with at most one workgroup per CU; deeper
+            // levels - many nodes, throughput-bound - keep their per-level launches)
+            int ncu = 256;
+            {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+            }
+            int nlv = 1;
+            while (nlv < pl->NL && (long)pl->lev[nlv].nodes.size() <= ncu) ++nlv;
+            pl->kc_levels = nlv;
+            const int cwt = pl->CWT;
+            const LevelData& lb = pl->lev[nlv - 1];
+            std::vector<int> kch(lb.nodes.size() * 8, 0);
+            std::vector<std::vector<int>> own(nlv);
+            for (int m = 0; m < nlv; ++m) own[m].assign(pl->lev[m].nodes.size(), -1);
+            for (size_t b = 0; b < lb.nodes.size(); ++b) {
+                int ch[8];
+                chain_of(lb.nodes[b], ch);
+                for (int k = 0; k < 8; ++k) kch[b * 8 + k] = ch[k];
+                for (int m = 0; m < nlv; ++m) if (own[m][ch[m]] < 0) own[m][ch[m]] = (int)b;
+            }
+            pl->kc_chain.upload(kch);
+            pl->kc_owner.clear();
+            pl->kc_owner.resize(nlv);
+            for (int m = 0; m < nlv; ++m) pl->kc_owner[m].upload(own[m]);
+            const long off = (long)cwt * cwt * ((nlv - 1) * (nlv - 2) / 2) + (long)(nlv - 1) * (cwt * (cwt - 1) / 2 + cwt);
+            pl->knot_chain_lds = (size_t)off * 2048 + (size_t)(cwt * (cwt + 1) / 2 + cwt) * FT_SZ * sizeof(double);
+            pl->knot_chain_ok = pl->knot_chain_lds <= 160 * 1024;
+        }
         std::vector<long> r0s, fwg0, lwg0;
         std::vector<int> chains, fwgn, tleaf, lwgn;
+        {
+            int ndev_cu = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ndev_cu = prop.multiProcessorCount;
+            size_t nparents = 0;
+            for (size_t t = 0; t < pl->leaf_nodes.size(); ++t)
+                if (t == 0 || pl->parent[pl->leaf_nodes[t]] != pl->parent[pl->leaf_nodes[t - 1]]) ++nparents;
+            pl->cascade_group_siblings = nparents >= (size_t)(2 * ndev_cu);
+        }
         for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
             const int i = pl->leaf_nodes[t];
             int ch[8];
             chain_of(i, ch);
-            lwg0.push_back((long)r0s.size()); lwgn.push_back((int)((pl->row1[i] - pl->row0[i]) / 16));
+            // one workgroup per leaf ... or per family of sibling leaves (same parent = same operand image on every level,
+            // staged once for all of them) when that still leaves at least two workgroups per CU
+            const bool join = pl->cascade_group_siblings && t > 0 && pl->parent[i] >= 0 && pl->parent[i] == pl->parent[pl->leaf_nodes[t - 1]] && !lwgn.empty();
+            if (join) lwgn.back() += (int)((pl->row1[i] - pl->row0[i]) / 16);
+            else { lwg0.push_back((long)r0s.size()); lwgn.push_back((int)((pl->row1[i] - pl->row0[i]) / 16)); }
             for (long p = pl->row0[i]; p < pl->row1[i]; p += 16) {
                 if (((p - pl->row0[i]) / 16) % pl->cascade_wpw == 0) {
                     fwg0.push_back((long)r0s.size());
@@ -841,6 +894,34 @@ static void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) {
     else launch_cascade<4, 4>(pl, ar);
 }
 
+template <int CWT, int NLMAX, int DIM, int MODE>
+static void launch_knot_chain_inst(mra_plan* pl, const KnotChainArgs& ka) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_knot_chain<CWT, NLMAX, DIM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_knot_chain<CWT, NLMAX, DIM, MODE>), dim3((unsigned)pl->lev[ka.nl - 1].nodes.size()), dim3(256), pl->knot_chain_lds,
+                       pl->stream, ka, pl->kp);
+}
+template <int CWT, int NLMAX>
+static void launch_knot_chain_cw(mra_plan* pl, const KnotChainArgs& ka) {
+    const int mode = pl->kp.mode;
+    if (pl->d == 1) {
+        if (mode == 0) launch_knot_chain_inst<CWT, NLMAX, 1, 0>(pl, ka);
+        else if (mode == 1) launch_knot_chain_inst<CWT, NLMAX, 1, 1>(pl, ka);
+        else if (mode == 2) launch_knot_chain_inst<CWT, NLMAX, 1, 2>(pl, ka);
+        else launch_knot_chain_inst<CWT, NLMAX, 1, 3>(pl, ka);
+    } else {
+        if (mode == 0) launch_knot_chain_inst<CWT, NLMAX, 2, 0>(pl, ka);
+        else if (mode == 1) launch_knot_chain_inst<CWT, NLMAX, 2, 1>(pl, ka);
+        else if (mode == 2) launch_knot_chain_inst<CWT, NLMAX, 2, 2>(pl, ka);
+        else launch_knot_chain_inst<CWT, NLMAX, 2, 3>(pl, ka);
+    }
+}
+static void launch_knot_chain(mra_plan* pl, const KnotChainArgs& ka) {
+    if (pl->CWT == 1) launch_knot_chain_cw<1, 8>(pl, ka);
+    else if (pl->CWT == 2) launch_knot_chain_cw<2, 8>(pl, ka);
+    else launch_knot_chain_cw<4, 4>(pl, ka);
+}
+
 // whole prior of a regular tree: per level a tiny knot pass (knot rows cascade -> kInv -> Cholesky),
 // then ONE cascade over all leaf row tiles that writes W once
 static double kernel_cov0(const mra_plan* pl) { return pl->kp.amp; }   // C(x,x) of every stationary kernel: amp * 1
@@ -855,7 +936,22 @@ static void run_prior_fused(mra_plan* pl) {
         base.coff[m] = pl->coff[m];
     }
     base.X = pl->X.p; base.W = pl->W.p; base.ldw = pl->ldw;
-    for (int m = 0; m < pl->NL; ++m) {
+    const int n_chain = (pl->use_knot_chain && pl->knot_chain_ok && pl->kc_levels >= 2) ? pl->kc_levels : 0;
+    if (n_chain) {
+        double fl = 0;
+        for (int m = 0; m < n_chain; ++m) fl += pl->lev[m].fl_pchol;
+        KTimer kt(pl, KF_PRIOR_CHOL, fl);
+        KnotChainArgs ka{};
+        for (int m = 0; m < n_chain; ++m) {
+            ka.lev[m] = base.lev[m];
+            ka.kt_rows[m] = pl->fl[m].kt_rows.p;
+            ka.owner[m] = pl->kc_owner[m].p;
+            ka.node_base[m] = (int)pl->level_ptr[m];
+        }
+        ka.chain = pl->kc_chain.p; ka.X = pl->X.p; ka.nl = n_chain; ka.err = pl->errflag.p;
+        launch_knot_chain(pl, ka);
+    }
+    for (int m = n_chain; m < pl->NL; ++m) {
         // one launch per level: knot rows cascade -> Wk, kInv, Cholesky factor, inverted diagonal blocks
         LevelData& lv = pl->lev[m];
         KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol);
@@ -873,7 +969,7 @@ static void run_prior_fused(mra_plan* pl) {
         for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_resid + pl->lev[m].fl_trsm;
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
-        ar.knot_mode = 0; ar.mlast = pl->NL - 1;
+        ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.dbg = pl->dbg;
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
         ar.ycol = pl->Ka; ar.y = pl->y.p;
         if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
@@ -1595,6 +1691,8 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
     if (option == 4) { pl->use_front_fused = value != 0; return MRA_OK; }
+    if (option == 5) { pl->use_knot_chain = value != 0; return MRA_OK; }
+    if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }
 

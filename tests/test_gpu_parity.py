@@ -344,6 +344,24 @@ def test_level_by_level_kernels_equal_fused_kernels(hip):
         pl.close()
 
 
+@pytest.mark.parametrize("name", ["g64m", "c2", "g128m"])
+def test_single_launch_chains_equal_per_level_launches(hip, name):
+    """MRA_OPT_KNOT_CHAIN (knot pass of all levels in one launch) and MRA_OPT_FRONT_FUSED (assembly + partial Cholesky +
+    Schur per level / children's Ut -> parent front in one launch) against the per-level launch sequences they replace."""
+    cs = K.load_case(name)
+    pl, lik, mean, var = run_hip(hip, cs)
+    for opts in ((4, 0), (5, 0), (4, 0, 5, 0)):
+        pl.set_option(4, 1); pl.set_option(5, 1)
+        for o, v in zip(opts[::2], opts[1::2]):
+            pl.set_option(o, v)
+        pl.run(True, True)
+        d, u = pl.likelihood()
+        m2, v2 = pl.predict()
+        assert abs(d + u - lik) <= 1e-12 * abs(lik), opts
+        assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10, opts
+    pl.close()
+
+
 @pytest.mark.parametrize("n,r,M,fused", [(128, 64, 3, True), (128, 64, 5, False), (96, 48, 2, True), (64, 16, 3, True)])
 def test_wide_blocks_and_deep_trees(hip, n, r, M, fused):
     """r0 = 64 (4 column tiles per level: C5-like) on the fused path (CWT=4) and, when the cascades'
