@@ -542,6 +542,159 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+//  Leaf-resident batched product: one workgroup (8 waves) per problem, C (=|-=) f(A B^T) with
+//    * every wave owning two 16-row tiles of A (rows w and w + 8 of each group of 16 row tiles): its A fragments
+//      come straight from global memory (32 contiguous bytes per lane, nobody else needs them),
+//    * B streamed through a double-buffered LDS stage, 16 k at a time, shared by all 8 waves,
+//    * up to LG_CT column tiles per pass held in registers (2 x 7 accumulators): 56 MFMAs per wave and barrier
+//      instead of the 16 of the 64x64-tile kernel above, whose operands also cross L2 four times more often.
+//  Accumulators come out in vec layout (lane (r,q): C[row r][4q .. 4q+3]): the epilogues move 32 bytes per lane.
+//  Same GemmProb, same SUB / COV epilogue semantics as k_gemm_nt_lds (used for the two big leaf products of the
+//  fused path: V[S,o] = kernel - W_S W_o^T and W[S,anc|y] -= Tt Ut^T; MRANode.py:73-80, 489-495 in factorised form).
+// ------------------------------------------------------------------------------------------------
+#define LG_CT 7
+#define LG_LD 20
+template <int EPI, int DIM, int MODE>
+__global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict__ probs, KernelParams kp) {
+    __shared__ __attribute__((aligned(16))) double sB[2][LG_CT * 16 * LG_LD];
+    __shared__ double sXB[LG_CT * 16 * DIM];
+    __shared__ int sIB[LG_CT * 16];
+    const GemmProb* __restrict__ pp = probs + blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwave = blockDim.x >> 6;                           // 4: two workgroups (two leaves) share a CU, one's epilogue
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;   // and prologue run beside the other's K loop
+    const int prow = pi16(r);
+    const int M = pp->M, N = pp->N, K = pp->K;
+    const int ntm = M >> 4, ntn = (N + 15) >> 4, nk = K >> 4;
+    const double* const A = pp->A; const long lda = pp->lda;
+    const double* const B = pp->B; const long ldb = pp->ldb;
+    const int* const idxB = pp->idxB;
+    double* const C = pp->C; const long ldc = pp->ldc;
+    const int zc = pp->zc;
+    const d4 zero = {0, 0, 0, 0};
+    for (int rg = 0; rg < ntm; rg += 2 * nwave) {
+        const int i0 = rg + wave, i1 = rg + wave + nwave;
+        const bool v0 = i0 < ntm, v1 = i1 < ntm;
+        const long row0 = (long)(v0 ? i0 : 0) * 16 + r, row1 = (long)(v1 ? i1 : 0) * 16 + r;
+        const double* a0p = A + row0 * lda + 4 * q;
+        const double* a1p = A + row1 * lda + 4 * q;
+        for (int j0 = 0; j0 < ntn; j0 += LG_CT) {
+            const int nc = min(LG_CT, ntn - j0);                 // column tiles of this pass
+            const int nchunk = nc * 64;                          // 32-byte chunks (row, 4 columns) of the staged nc*16 x 16 slab
+            // staging role: up to two chunks per thread
+            const int e0 = threadIdx.x, e1 = threadIdx.x + blockDim.x;
+            const bool on0 = e0 < nchunk, on1 = e1 < nchunk;
+            const int sr0 = e0 >> 2, sc0 = (e0 & 3) << 2, sr1 = e1 >> 2, sc1 = (e1 & 3) << 2;
+            long br0 = j0 * 16 + sr0, br1 = j0 * 16 + sr1;
+            bool ok0 = on0 && br0 < N, ok1 = on1 && br1 < N;
+            if (ok0 && idxB) { const int ib = gldi(idxB + br0); ok0 = ib >= 0; br0 = ib; }
+            if (ok1 && idxB) { const int ib = gldi(idxB + br1); ok1 = ib >= 0; br1 = ib; }
+            const double* bp0 = B + (ok0 ? br0 : 0) * ldb + sc0;
+            const double* bp1 = B + (ok1 ? br1 : 0) * ldb + sc1;
+            __syncthreads();                                     // previous pass is done with sB / sXB / sIB
+            if (EPI == EPI_COV || EPI == EPI_HOSTCOV) {
+                for (int t = threadIdx.x; t < nc * 16; t += blockDim.x) {
+                    const int col = j0 * 16 + t;
+                    const int ib = col < N ? (idxB ? gldi(idxB + col) : col) : -1;
+                    sIB[t] = ib;
+                    if (EPI == EPI_COV) {
+#pragma unroll
+                        for (int c = 0; c < DIM; ++c) sXB[t * DIM + c] = gld(pp->XB + (long)(ib < 0 ? 0 : ib) * DIM + c);
+                    }
+                }
+            }
+            d4 acc0[LG_CT], acc1[LG_CT];
+#pragma unroll
+            for (int j = 0; j < LG_CT; ++j) { acc0[j] = zero; acc1[j] = zero; }
+            if (EPI == EPI_SUB) {
+                // the C tiles go straight into the accumulators (negated; the epilogue writes -acc = C_in - A B^T): their
+                // loads are in flight beside the first chunk and cost no registers
+#pragma unroll
+                for (int j = 0; j < LG_CT; ++j) {
+                    if (j < nc) {
+                        const int col = (j0 + j) * 16 + 4 * q;
+                        if (!(zc > 0 && col >= zc)) {
+                            if (v0) acc0[j] = -gld4(C + row0 * ldc + col);
+                            if (v1) acc1[j] = -gld4(C + row1 * ldc + col);
+                        }
+                    }
+                }
+            }
+            d4 sb0 = zero, sb1 = zero, fa0 = zero, fa1 = zero;
+            if (nk > 0) { sb0 = gld4(bp0); sb1 = gld4(bp1); fa0 = gld4(a0p); fa1 = gld4(a1p); }
+            if (on0) *(d4*)(&sB[0][sr0 * LG_LD + sc0]) = ok0 ? sb0 : zero;
+            if (on1) *(d4*)(&sB[0][sr1 * LG_LD + sc1]) = ok1 ? sb1 : zero;
+            __syncthreads();
+            for (int ks = 0; ks < nk; ++ks) {
+                const int cur = ks & 1;
+                const int kn = (ks + 1 < nk ? ks + 1 : ks) * 16;
+                const d4 a0 = fa0, a1 = fa1;
+                sb0 = gld4(bp0 + kn); sb1 = gld4(bp1 + kn); fa0 = gld4(a0p + kn); fa1 = gld4(a1p + kn);   // next chunk in flight
+#pragma unroll
+                for (int j = 0; j < LG_CT; ++j) {
+                    if (j < nc) {
+                        const d4 b = *(const d4*)(&sB[cur][(j * 16 + prow) * LG_LD + 4 * q]);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            acc0[j] = mfma16(b[s4], a0[s4], acc0[j]);
+                            acc1[j] = mfma16(b[s4], a1[s4], acc1[j]);
+                        }
+                    }
+                }
+                if (ks + 1 < nk) {
+                    if (on0) *(d4*)(&sB[cur ^ 1][sr0 * LG_LD + sc0]) = ok0 ? sb0 : zero;
+                    if (on1) *(d4*)(&sB[cur ^ 1][sr1 * LG_LD + sc1]) = ok1 ? sb1 : zero;
+                    __syncthreads();
+                }
+            }
+            // ---- epilogue: lane (r,q) of tile (i,j) holds C[i*16 + r][j*16 + 4q .. 4q+3]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool vh = h ? v1 : v0;
+                if (!vh) continue;
+                const long row = h ? row1 : row0;
+                double xa[DIM];
+                int op = -1;
+                if (EPI == EPI_COV) {
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) xa[c] = gld(pp->XA + row * DIM + c);
+                }
+                if (EPI == EPI_COV || EPI == EPI_HOSTCOV) op = pp->rowmap ? gldi(pp->rowmap + row) : -1;
+#pragma unroll
+                for (int j = 0; j < LG_CT; ++j) {
+                    if (j < nc) {
+                        const d4 acc = h ? acc1[j] : acc0[j];
+                        const int col = (j0 + j) * 16 + 4 * q;
+                        double* cp = C + row * ldc + col;
+                        d4 v;
+                        if (EPI == EPI_SET) v = acc;
+                        else if (EPI == EPI_SUB) v = -acc;
+                        else {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const int lc = j * 16 + 4 * q + s4;
+                                const int ib = sIB[lc];
+                                double cv;
+                                if (EPI == EPI_COV) cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, &sXB[lc * DIM], kp.circular));
+                                else cv = gld(pp->Csrc + row * pp->ldcs + col + s4);
+                                v[s4] = ib < 0 ? 0.0 : cv - acc[s4];
+                            }
+                            if (op >= 0) {
+                                d4 v2 = v;
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4) v2[s4] += (op == col + s4) ? pp->diag_add : 0.0;
+                                gst4(pp->C2 + (long)op * ldc + col, v2);
+                            }
+                        }
+                        gst4(cp, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 //  16x16 diagonal block: Cholesky + inverse of the factor, one row per lane (lanes 0..15)
 // ------------------------------------------------------------------------------------------------
 // a[k] = T[lane][k] (k <= lane valid, 0 above the diagonal).  On return a[k] = L[lane][k] (0 above the

@@ -205,7 +205,7 @@ struct mra_plan {
     int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
     // fused ("regular tree") path
-    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true;
+    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true;
     int dbg = 0;
     int NL = 0, CWT = 0;
     struct FusedLevel {
@@ -828,6 +828,18 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
     }
 }
 
+// leaf-resident product (one workgroup per problem): the two big leaf GEMMs of a pass
+template <int EPI>
+static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) {
+    if (!nprob) return;
+    const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
+    const dim3 grid((unsigned)nprob), block(256);
+#define MRA_LG_LAUNCH(D, MD) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, block, 0, pl->stream, probs, pl->kp)
+    if (pl->d == 1) { if (mode == 0) MRA_LG_LAUNCH(1, 0); else if (mode == 1) MRA_LG_LAUNCH(1, 1); else if (mode == 2) MRA_LG_LAUNCH(1, 2); else MRA_LG_LAUNCH(1, 3); }
+    else { if (mode == 0) MRA_LG_LAUNCH(2, 0); else if (mode == 1) MRA_LG_LAUNCH(2, 1); else if (mode == 2) MRA_LG_LAUNCH(2, 2); else MRA_LG_LAUNCH(2, 3); }
+#undef MRA_LG_LAUNCH
+}
+
 static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob) {
     if (!nprob) return;
     hipLaunchKernelGGL(k_panel_chol, dim3((unsigned)nprob), dim3(256), 0, pl->stream, probs, pl->dnode.p, pl->errflag.p);
@@ -1295,8 +1307,12 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         const bool c_only = !pred && fused && pl->gemm_lds && pl->leaf_max_nop / 16 <= 12;
         {
             KTimer kt(pl, KF_LEAF_RESID, c_only ? 0.0 : pl->fl_leaf_resid);
-            if (pl->host_cov) launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
+            if (pl->host_cov) {
+                if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl);
+                else launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
+            }
             else if (c_only) launch_gemm<EPI_COV>(pl, pl->gLeafResidLik.p, nl, pl->leaf_max_nop, pl->leaf_max_nop);
+            else if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl);
             else launch_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
         }
         if (pl->leaf_max_nop > 0) {
@@ -1366,7 +1382,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                                    pl->row_leaf.p, pl->W.p, (long)pl->ldw, pl->Ka, pl->var.p, cov0,
                                    pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
             }
-            { KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update); launch_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl, pl->leaf_max_rows, pl->leaf_max_na); }
+            {
+                KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
+                if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl);
+                else launch_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl, pl->leaf_max_rows, pl->leaf_max_na);
+            }
             if (side) {
                 pl->stream = main_stream;
                 HIP_TRY(hipEventRecord(pl->ev_join, pl->stream2));
@@ -1692,6 +1712,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
     if (option == 4) { pl->use_front_fused = value != 0; return MRA_OK; }
     if (option == 5) { pl->use_knot_chain = value != 0; return MRA_OK; }
+    if (option == 6) { pl->use_leaf_gemm = value != 0; return MRA_OK; }
     if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }

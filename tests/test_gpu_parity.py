@@ -346,12 +346,13 @@ def test_level_by_level_kernels_equal_fused_kernels(hip):
 
 @pytest.mark.parametrize("name", ["g64m", "c2", "g128m"])
 def test_single_launch_chains_equal_per_level_launches(hip, name):
-    """MRA_OPT_KNOT_CHAIN (knot pass of all levels in one launch) and MRA_OPT_FRONT_FUSED (assembly + partial Cholesky +
-    Schur per level / children's Ut -> parent front in one launch) against the per-level launch sequences they replace."""
+    """MRA_OPT_KNOT_CHAIN (knot pass of all levels in one launch), MRA_OPT_FRONT_FUSED (assembly + partial Cholesky +
+    Schur per level / children's Ut -> parent front in one launch) and MRA_OPT_LEAF_GEMM (leaf-resident products) against
+    the launch sequences / kernels they replace."""
     cs = K.load_case(name)
     pl, lik, mean, var = run_hip(hip, cs)
-    for opts in ((4, 0), (5, 0), (4, 0, 5, 0)):
-        pl.set_option(4, 1); pl.set_option(5, 1)
+    for opts in ((4, 0), (5, 0), (6, 0), (4, 0, 5, 0, 6, 0)):
+        pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1)
         for o, v in zip(opts[::2], opts[1::2]):
             pl.set_option(o, v)
         pl.run(True, True)
