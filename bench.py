@@ -20,8 +20,8 @@ the rendezvous, the barriers and the max-over-ranks of the timings.
 loop pays per evaluation; "value_end_to_end" is the same node count over the wall-clock of the drop-in constructor
 MRATree(...) + getLikelihood() + predict() (host tree replay + uploads + device pass + download), the quantity
 SURVEY.md section 8(d) defines for the reference.  Extra objects in the JSON line: "roofline" (dominant kernel,
-hipEvent-timed inside the timed steps; "peak" is the datasheet FP64 matrix rate, "peak_measured" the rate of an
-LDS-fed register-blocked v_mfma_f64_16x16x4 loop on this GPU, profiles/r02_mfma_f64_microbench.txt), "cpu_baseline"
+hipEvent-timed inside the timed steps; "peak" is the datasheet FP64 matrix rate, "peak_measured" the back-to-back
+v_mfma_f64_16x16x4 rate measured on this GPU, profiles/r02_mfma_f64_peak_microbench.txt), "cpu_baseline"
 (N=1, rank 0: the faithful NumPy/SciPy restatement of the reference timed on a bounded sample of the same tree, with
 and without the reference's per-node gc.collect() and with one BLAS thread), "host" (set-up timings).
 
@@ -40,7 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (= vector) peak; DESIGN.md section 5
-FP64_MFMA_MEASURED_TFLOPS = 76.5  # LDS-fed 2x2 register-blocked v_mfma_f64_16x16x4 loop, 2 workgroups/CU (tools/mfma_f64_4x4.hip)
+FP64_MFMA_MEASURED_TFLOPS = 77.3  # back-to-back v_mfma_f64_16x16x4 on this GPU: 64.0 cycles per instruction per SIMD at 2.39 GHz
+                                  # (tools/mfma_f64_peak.hip, profiles/r02_mfma_f64_peak_microbench.txt)
 HBM_PEAK_GBS = 8000.0
 
 CONFIGS = {

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and enum values only: the library itself is loaded with dlopen at run time
@@ -36,7 +37,24 @@ static void derive_kernel_params(KernelParams& kp) {
     kp.c_inv_l = c / kp.l;
 }
 
-#define MRA_VERSION_STR "mra_hip 0.1 (gfx950)"
+#define MRA_VERSION_STR "mra_hip 0.2 (gfx950)"
+
+// ---- host dry run (test instrumentation, never a compute path) ------------------------------------------------------
+// With MRA_HOST_DRYRUN=1 in the environment the plan is built entirely in host memory: every "device" buffer is a
+// malloc, uploads are memcpy, no stream / event / kernel is ever created and mra_run refuses to run.  The point is
+// to push the ~1500 lines of index arithmetic of plan construction (build_static, build_leaf, the host-cov block
+// bookkeeping) and the native tree replay through AddressSanitizer / UBSan on a machine without a GPU
+// (`make asan`, tests/test_asan_host.py).  Nothing is computed in this mode.
+static const bool g_dry = []() { const char* e = getenv("MRA_HOST_DRYRUN"); return e && e[0] == '1'; }();
+static inline hipError_t mraMalloc(void** p, size_t n) { if (g_dry) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; } return hipMalloc(p, n); }
+static inline hipError_t mraFree(void* p) { if (g_dry) { free(p); return hipSuccess; } return hipFree(p); }
+static inline hipError_t mraMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind k) { if (g_dry) { memcpy(d, s_, n); return hipSuccess; } return hipMemcpy(d, s_, n, k); }
+static inline hipError_t mraMemset(void* d, int v, size_t n) { if (g_dry) { memset(d, v, n); return hipSuccess; } return hipMemset(d, v, n); }
+static inline hipError_t mraMemcpy2D(void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) {
+    if (g_dry) { for (size_t i = 0; i < h; ++i) memcpy((char*)d + i * dp, (const char*)s_ + i * sp, w); return hipSuccess; }
+    return hipMemcpy2D(d, dp, s_, sp, w, h, k);
+}
+static inline hipError_t mraSetDevice(int dev) { return g_dry ? hipSuccess : hipSetDevice(dev); }
 
 static thread_local std::string g_last_error;
 
@@ -65,25 +83,25 @@ enum KFam {
 // [1] general level-by-level path.  tools/summarize_profiles.py maps the trace's kernel names onto the same strings.
 static const char* kfam_name[2][KF_COUNT] = {
     {"k_gemm_nt_lds<COV> prior residual (unused on the fused path)",
-     "k_prior_cascade knot pass (knot rows + kInv + Cholesky, one launch per level)",
+     "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)",
      "k_prior_cascade row pass (W of all levels, Ut scatter)",
-     "k_gemm_nt_lds<COV> leaf residual V[S,o] and C",
+     "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
-     "k_gemm_nt<SET> parent fronts from Ut (segmented SYRK)",
-     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
-     "k_panel_chol front partial Cholesky",
-     "k_gemm_nt<SUB> front Schur complement",
+     "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)",
+     "k_leaf_gemm<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_front (assembly + partial Cholesky + Schur per level)",
+     "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)",
      "k_trsm_rows2 predict (unused on the fused path)",
      "k_predict_cascade (all levels, mean/var)",
      "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"},
     {"k_gemm_nt_lds<COV> prior residual per level",
      "k_panel_chol prior kInv Cholesky per level",
      "k_trsm_rows2 prior W = R L^-T per level",
-     "k_gemm_nt_lds<COV> leaf residual V[S,o] and C",
+     "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
-     "k_gemm_nt<SET> leaf / parent SYRK",
-     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
-     "k_panel_chol front partial Cholesky",
+     "k_gemm_nt<SET> / k_parent_front leaf or parent SYRK",
+     "k_leaf_gemm<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_front / k_panel_chol front partial Cholesky",
      "k_gemm_nt<SUB> front Schur complement",
      "k_trsm_rows2 predict X = W Lt^-T per level",
      "k_gemm_nt_lds<SUB> predict update per level",
@@ -97,14 +115,14 @@ struct DevVec {
         release();
         n = h.size();
         if (n) {
-            if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
-            if (hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
+            if (mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
+            if (mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
         }
     }
     void alloc(size_t count) {
         release();
         n = count;
-        if (n && hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
+        if (n && mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
             char b[160];
             snprintf(b, sizeof b, "hipMalloc of %.3f GB failed", (double)(n * sizeof(T)) / 1e9);
             p = nullptr;
@@ -112,7 +130,7 @@ struct DevVec {
         }
     }
     void release() {
-        if (p) hipFree(p);
+        if (p) mraFree(p);
         p = nullptr;
         n = 0;
     }
@@ -296,10 +314,10 @@ static void build_static(mra_plan* pl) {
     pl->dnode.alloc(pl->n_nodes);
     pl->scal.alloc(4);
     pl->errflag.alloc(1);
-    HIP_TRY(hipMemset(pl->errflag.p, 0, sizeof(int)));       // k_sum_dnode reads it and clears it again at the end of every pass
-    HIP_TRY(hipMemset(pl->W.p, 0, pl->W.n * sizeof(double)));
-    HIP_TRY(hipMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
-    HIP_TRY(hipMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
+    HIP_TRY(mraMemset(pl->errflag.p, 0, sizeof(int)));       // k_sum_dnode reads it and clears it again at the end of every pass
+    HIP_TRY(mraMemset(pl->W.p, 0, pl->W.n * sizeof(double)));
+    HIP_TRY(mraMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
+    HIP_TRY(mraMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
     pl->knots_dev.upload(pl->knot_rows);
 
     // knot index arrays for the gather side of the prior GEMM (padded to cw with -1)
@@ -545,7 +563,7 @@ static void build_static(mra_plan* pl) {
             int ncu = 256;
             {
                 hipDeviceProp_t prop;
-                if (hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+                if (!g_dry && hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
             }
             int nlv = 1;
             while (nlv < pl->NL && (long)pl->lev[nlv].nodes.size() <= ncu) ++nlv;
@@ -574,7 +592,7 @@ static void build_static(mra_plan* pl) {
         {
             int ndev_cu = 256;
             hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ndev_cu = prop.multiProcessorCount;
+            if (!g_dry && hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ndev_cu = prop.multiProcessorCount;
             size_t nparents = 0;
             for (size_t t = 0; t < pl->leaf_nodes.size(); ++t)
                 if (t == 0 || pl->parent[pl->leaf_nodes[t]] != pl->parent[pl->leaf_nodes[t - 1]]) ++nparents;
@@ -707,7 +725,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->leaf_ut.upload(uts);
         pl->leaf_nop_dev.upload(pl->leaf_nop);
         // the Ut blocks start from zero: rows of the y block beyond y itself and phantom observation columns stay zero
-        if (pl->panel.n) HIP_TRY(hipMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
+        if (pl->panel.n) HIP_TRY(mraMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
     }
     pl->parent_syrk = false;
     pl->hLeafSyrk = gs;
@@ -1247,9 +1265,10 @@ static void ensure_gt(mra_plan* pl) {
 }
 
 static void run_all(mra_plan* pl, uint32_t flags) {
+    if (g_dry) throw MraError(MRA_ERR_STATE, "MRA_HOST_DRYRUN plan: built in host memory for the sanitizers, it cannot run");
     if (!(pl->have_locs && pl->have_obs && pl->have_kernel))
         throw MraError(MRA_ERR_STATE, "mra_run needs set_locs, set_obs and set_kernel first");
-    HIP_TRY(hipSetDevice(pl->device));
+    HIP_TRY(mraSetDevice(pl->device));
     if (pl->pass_open) {
         // the previous pass never reached finish_run (an error was thrown, or a split run was abandoned before
         // mra_run_resume): wait for whatever it left on the two streams, and clear the device error flag that
@@ -1422,10 +1441,12 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
         if (t->P <= 0 || (t->d != 1 && t->d != 2) || t->n_levels <= 0 || t->n_nodes <= 0)
             throw MraError(MRA_ERR_INVALID, "bad topology header");
         int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-            throw MraError(MRA_ERR_HIP, "no HIP device available: libmra_hip needs an AMD GPU (gfx950); there is no CPU fallback");
-        if (device < 0 || device >= ndev) throw MraError(MRA_ERR_INVALID, "device ordinal out of range");
-        HIP_TRY(hipSetDevice(device));
+        if (!g_dry) {
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+                throw MraError(MRA_ERR_HIP, "no HIP device available: libmra_hip needs an AMD GPU (gfx950); there is no CPU fallback");
+            if (device < 0 || device >= ndev) throw MraError(MRA_ERR_INVALID, "device ordinal out of range");
+        }
+        HIP_TRY(mraSetDevice(device));
         pl = new mra_plan();
         pl->device = device;
         pl->P = t->P; pl->d = t->d; pl->n_levels = t->n_levels; pl->n_nodes = t->n_nodes;
@@ -1440,7 +1461,7 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
         pl->knot_rows.assign(t->knot_rows, t->knot_rows + pl->knot_ptr.back());
         pl->cw.assign(t->cw, t->cw + t->n_levels);
         if (pl->level_ptr[0] != 0 || pl->level_ptr.back() != t->n_nodes) throw MraError(MRA_ERR_INVALID, "level_ptr inconsistent");
-        {
+        if (!g_dry) {
             // The leaf update (one large GEMM) and [parent SYRK -> front Cholesky/Schur chain -> all-reduce of a sharded run]
             // only meet again in the predictive cascade: they are issued on two streams, so the collective and the
             // latency-bound chain never wait behind the update.  (On one GPU the update keeps every SIMD's register file
@@ -1452,7 +1473,7 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
             HIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         }
-        for (int k = 0; k < 6; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
+        for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
         build_static(pl);
         *out = pl;
         return MRA_OK;
@@ -1469,7 +1490,7 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
 
 int mra_plan_destroy(mra_plan* pl) {
     if (!pl) return MRA_OK;
-    hipSetDevice(pl->device);
+    mraSetDevice(pl->device);
     if (pl->comm && pl->rccl) {
         typedef ncclResult_t (*destroy_t)(ncclComm_t);
         destroy_t fn = (destroy_t)dlsym(pl->rccl, "ncclCommDestroy");
@@ -1488,8 +1509,8 @@ int mra_plan_destroy(mra_plan* pl) {
 int mra_plan_set_locs(mra_plan* pl, const double* locs) {
     if (!pl || !locs) return MRA_ERR_INVALID;
     try {
-        HIP_TRY(hipSetDevice(pl->device));
-        HIP_TRY(hipMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(mraSetDevice(pl->device));
+        HIP_TRY(mraMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
         if (pl->regular) {
             const int cw = pl->cw[0];
             for (int m = 0; m < pl->NL; ++m) {
@@ -1504,7 +1525,7 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
                         for (int k = 0; k < pl->d; ++k)
                             kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
                 }
-                HIP_TRY(hipMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIP_TRY(mraMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
             }
         }
         pl->have_locs = true;
@@ -1516,8 +1537,8 @@ int mra_plan_set_obs(mra_plan* pl, const double* y, double R) {
     if (!pl || !y) return MRA_ERR_INVALID;
     try {
         if (!(R > 0.0)) throw MraError(MRA_ERR_INVALID, "R must be a positive scalar");
-        HIP_TRY(hipSetDevice(pl->device));
-        HIP_TRY(hipMemcpy(pl->y.p, y, (size_t)pl->P * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(mraSetDevice(pl->device));
+        HIP_TRY(mraMemcpy(pl->y.p, y, (size_t)pl->P * sizeof(double), hipMemcpyHostToDevice));
         pl->R = R;
         if (pl->host_cov) {
             // host-evaluated covariance blocks are per observed row: a new observation pattern invalidates them (and
@@ -1544,7 +1565,7 @@ int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
     try {
         if (kind == MRA_KERNEL_HOST) {
             if (!pl->have_obs) throw MraError(MRA_ERR_STATE, "MRA_KERNEL_HOST needs mra_plan_set_obs first (leaf blocks are per observed row)");
-            HIP_TRY(hipSetDevice(pl->device));
+            HIP_TRY(mraSetDevice(pl->device));
             // one padded block per node: non-leaf N_j x cw, leaf N_j x nop; leaves also C(x,x) per row
             pl->cov_off.assign(pl->n_nodes + 1, 0);
             for (int i = 0; i < pl->n_nodes; ++i) {
@@ -1554,8 +1575,8 @@ int mra_plan_set_kernel(mra_plan* pl, int kind, const double* params, int n) {
             }
             pl->covsrc.alloc(std::max<long>(pl->cov_off.back(), 1));
             pl->covdiag.alloc(pl->P);
-            HIP_TRY(hipMemset(pl->covsrc.p, 0, pl->covsrc.n * sizeof(double)));
-            HIP_TRY(hipMemset(pl->covdiag.p, 0, pl->covdiag.n * sizeof(double)));
+            HIP_TRY(mraMemset(pl->covsrc.p, 0, pl->covsrc.n * sizeof(double)));
+            HIP_TRY(mraMemset(pl->covdiag.p, 0, pl->covdiag.n * sizeof(double)));
             for (int m = 0; m < pl->n_levels; ++m) {
                 LevelData& lv = pl->lev[m];
                 for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
@@ -1591,7 +1612,7 @@ int mra_plan_set_cov_block(mra_plan* pl, int32_t node, const double* C, int64_t 
     try {
         if (!pl->host_cov) throw MraError(MRA_ERR_STATE, "select MRA_KERNEL_HOST with mra_plan_set_kernel first");
         if (node < 0 || node >= pl->n_nodes) throw MraError(MRA_ERR_INVALID, "node out of range");
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         const long nr = pl->row1[node] - pl->row0[node];
         long ld, want_cols;
         if (pl->leaf[node]) {
@@ -1607,9 +1628,9 @@ int mra_plan_set_cov_block(mra_plan* pl, int32_t node, const double* C, int64_t 
             throw MraError(MRA_ERR_INVALID, b);
         }
         if (n_cols > 0)
-            HIP_TRY(hipMemcpy2D(pl->covsrc.p + pl->cov_off[node], ld * sizeof(double), C, n_cols * sizeof(double),
+            HIP_TRY(mraMemcpy2D(pl->covsrc.p + pl->cov_off[node], ld * sizeof(double), C, n_cols * sizeof(double),
                                 n_cols * sizeof(double), nr, hipMemcpyHostToDevice));
-        if (diag) HIP_TRY(hipMemcpy(pl->covdiag.p + pl->row0[node], diag, nr * sizeof(double), hipMemcpyHostToDevice));
+        if (diag) HIP_TRY(mraMemcpy(pl->covdiag.p + pl->row0[node], diag, nr * sizeof(double), hipMemcpyHostToDevice));
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }
@@ -1627,7 +1648,7 @@ int mra_run_resume(mra_plan* pl) {
     if (!pl) return MRA_ERR_INVALID;
     try {
         if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         run_fronts_and_predict(pl, pl->reduce_level, true);
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
@@ -1644,9 +1665,9 @@ int mra_get_predict(mra_plan* pl, double* mean, double* var) {
     if (!pl || !mean || !var) return MRA_ERR_INVALID;
     try {
         if (!pl->ran || !(pl->run_flags & MRA_RUN_PREDICT)) throw MraError(MRA_ERR_STATE, "mra_run with MRA_RUN_PREDICT has not completed");
-        HIP_TRY(hipSetDevice(pl->device));
-        HIP_TRY(hipMemcpy(mean, pl->mean.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(var, pl->var.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(mraSetDevice(pl->device));
+        HIP_TRY(mraMemcpy(mean, pl->mean.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(mraMemcpy(var, pl->var.p, (size_t)pl->P * sizeof(double), hipMemcpyDeviceToHost));
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }
@@ -1654,13 +1675,13 @@ int mra_get_predict(mra_plan* pl, double* mean, double* var) {
 int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_avail) {
     if (!pl || !n_avail) return MRA_ERR_INVALID;
     try {
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         const double* src = nullptr; int64_t n = 0;
         if (what == 0) { src = pl->W.p; n = (int64_t)pl->W.n; }
         else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
         else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
         *n_avail = n;
-        if (out && cap > 0) HIP_TRY(hipMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
+        if (out && cap > 0) HIP_TRY(mraMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }
@@ -1670,7 +1691,7 @@ int mra_get_node_block(mra_plan* pl, int32_t node, int what, double* out, int64_
     try {
         if (node < 0 || node >= pl->n_nodes) throw MraError(MRA_ERR_INVALID, "node out of range");
         if (!pl->ran) throw MraError(MRA_ERR_STATE, "mra_run has not completed");
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         const int m = pl->node_level[node];
         const double* src = nullptr;
         int64_t rows = 0, cols = 0, ld = 0;
@@ -1692,7 +1713,7 @@ int mra_get_node_block(mra_plan* pl, int32_t node, int what, double* out, int64_
         } else throw MraError(MRA_ERR_INVALID, "unknown block id");
         *n_rows = rows; *n_cols = cols;
         const int64_t n = std::min<int64_t>(cap, rows * cols);
-        if (out && n > 0) HIP_TRY(hipMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        if (out && n > 0) HIP_TRY(mraMemcpy(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
         (void)ld;
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
@@ -1746,15 +1767,15 @@ int mra_eval_kernel(int kind, const double* params, int n_params, const double* 
     kp.circular = (n_params >= 4 && params[3] != 0.0) ? 1 : 0;
     derive_kernel_params(kp);
     double *dD = nullptr, *dO = nullptr;
-    if (hipMalloc((void**)&dD, n * sizeof(double)) != hipSuccess || hipMalloc((void**)&dO, n * sizeof(double)) != hipSuccess) {
+    if (mraMalloc((void**)&dD, n * sizeof(double)) != hipSuccess || mraMalloc((void**)&dO, n * sizeof(double)) != hipSuccess) {
         g_last_error = "hipMalloc failed (no GPU?)";
-        if (dD) hipFree(dD);
+        if (dD) mraFree(dD);
         return MRA_ERR_HIP;
     }
-    hipMemcpy(dD, D, n * sizeof(double), hipMemcpyHostToDevice);
+    mraMemcpy(dD, D, n * sizeof(double), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dD, dO, (long)n, kp);
-    hipError_t e = hipMemcpy(out, dO, n * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dD); hipFree(dO);
+    hipError_t e = mraMemcpy(out, dO, n * sizeof(double), hipMemcpyDeviceToHost);
+    mraFree(dD); mraFree(dO);
     if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return MRA_ERR_HIP; }
     return MRA_OK;
 }
@@ -1814,10 +1835,10 @@ int mra_reduce_export(mra_plan* pl, double* out) {
     if (!pl || !out) return MRA_ERR_INVALID;
     try {
         if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         HIP_TRY(hipStreamSynchronize(pl->stream));
         LevelData& lv = pl->lev[pl->reduce_level];
-        HIP_TRY(hipMemcpy(out, lv.F.p, lv.F.n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(mraMemcpy(out, lv.F.p, lv.F.n * sizeof(double), hipMemcpyDeviceToHost));
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }
@@ -1826,9 +1847,9 @@ int mra_reduce_import(mra_plan* pl, const double* in) {
     if (!pl || !in) return MRA_ERR_INVALID;
     try {
         if (!pl->split_pending) throw MraError(MRA_ERR_STATE, "no split run pending");
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         LevelData& lv = pl->lev[pl->reduce_level];
-        HIP_TRY(hipMemcpy(lv.F.p, in, lv.F.n * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(mraMemcpy(lv.F.p, in, lv.F.n * sizeof(double), hipMemcpyHostToDevice));
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }
@@ -1847,7 +1868,7 @@ int mra_comm_unique_id(char* out, int cap) {
 int mra_comm_init(mra_plan* pl, const char* uid, int n_ranks, int rank) {
     if (!pl || !uid) return MRA_ERR_INVALID;
     try {
-        HIP_TRY(hipSetDevice(pl->device));
+        HIP_TRY(mraSetDevice(pl->device));
         pl->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!pl->rccl) pl->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!pl->rccl) throw MraError(MRA_ERR_COMM, "cannot load librccl.so");

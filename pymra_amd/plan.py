@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmra_hip.so")
+# PYMRA_AMD_LIB: another build of the same library (tests/test_asan_host.py points it at the host-sanitizer build)
+LIB_PATH = os.environ.get("PYMRA_AMD_LIB") or os.path.join(_HERE, "libmra_hip.so")
 
 MRA_RUN_LIKELIHOOD = 1
 MRA_RUN_PREDICT = 2

@@ -17,17 +17,18 @@ if ks:
 def family(name, grid, maxgrid):
     """rocprof kernel name (+ grid) -> bench.py kernel family name (mra_plan.hip kfam_name[0], the fused path)"""
     if name.startswith("void k_prior_cascade"):
-        return "k_prior_cascade row pass (W of all levels, Ut scatter)" if grid == maxgrid.get("cascade") else \
-               "k_prior_cascade knot pass (knot rows + kInv + Cholesky, one launch per level)"
+        return "k_prior_cascade row pass (W of all levels, Ut scatter)" if grid == maxgrid.get("cascade") else KNOT
+    if name.startswith("void k_knot_chain"): return KNOT
     if name.startswith("void k_predict_cascade"): return "k_predict_cascade (all levels, mean/var)"
-    if name.startswith("void k_gemm_nt_lds<2"): return "k_gemm_nt_lds<COV> leaf residual V[S,o] and C" if grid == maxgrid.get("cov") else SMALL
-    if name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut"
-    if name.startswith("void k_gemm_nt<0"): return "k_gemm_nt<SET> parent fronts from Ut (segmented SYRK)"
-    if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front Schur complement"
+    if name.startswith("void k_leaf_gemm<2"): return "k_leaf_gemm<COV> leaf residual V[S,o] and C"
+    if name.startswith("void k_leaf_gemm<1"): return "k_leaf_gemm<SUB> leaf update W[S,anc] -= Tt^T Ut"
+    if name.startswith("void k_parent_front"): return "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)"
+    if name.startswith("void k_front"): return "k_front (assembly + partial Cholesky + Schur per level)"
+    if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)"
     if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)"
-    if name.startswith("k_panel_chol"): return "k_panel_chol front partial Cholesky"
     return SMALL
 
+KNOT = "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)"
 SMALL = "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"
 
 # per-family launch durations from the kernel trace of the --stats run (the stats CSV aggregates by kernel NAME, and one
@@ -41,7 +42,7 @@ if kt:
     for r in rows:
         n, g = r["Kernel_Name"], gs(r)
         if n.startswith("void k_prior_cascade"): mg["cascade"] = max(mg.get("cascade", 0), g)
-        if n.startswith("void k_gemm_nt_lds<2"): mg["cov"] = max(mg.get("cov", 0), g)
+        pass
     fam_d = collections.defaultdict(list)
     for r in rows:
         fam_d[family(r["Kernel_Name"], gs(r), mg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -58,7 +59,7 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     for r in rows:
         n, g = r["Kernel_Name"], int(r["Grid_Size"])
         if n.startswith("void k_prior_cascade"): mg["cascade"] = max(mg.get("cascade", 0), g)
-        if n.startswith("void k_gemm_nt_lds<2"): mg["cov"] = max(mg.get("cov", 0), g)
+        pass
     acc = collections.defaultdict(list)
     disp = collections.defaultdict(set)
     for r in rows:
