@@ -552,13 +552,14 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
 //  Same GemmProb, same SUB / COV epilogue semantics as k_gemm_nt_lds (used for the two big leaf products of the
 //  fused path: V[S,o] = kernel - W_S W_o^T and W[S,anc|y] -= Tt Ut^T; MRANode.py:73-80, 489-495 in factorised form).
 // ------------------------------------------------------------------------------------------------
-#define LG_CT 7
 #define LG_LD 20
-template <int EPI, int DIM, int MODE>
+// RT row tiles per wave, CT column tiles per pass: <2, 7> for the leaf residual (N = observations, <= 7 tiles in one pass at
+// C3), <1, 13> for the leaf update (N = ancestors + y = 13 tiles: one pass, so that Tt is read from HBM once)
+template <int EPI, int DIM, int MODE, int RT, int CT>
 __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict__ probs, KernelParams kp) {
-    __shared__ __attribute__((aligned(16))) double sB[2][LG_CT * 16 * LG_LD];
-    __shared__ double sXB[LG_CT * 16 * DIM];
-    __shared__ int sIB[LG_CT * 16];
+    __shared__ __attribute__((aligned(16))) double sB[2][CT * 16 * LG_LD];
+    __shared__ double sXB[CT * 16 * DIM];
+    __shared__ int sIB[CT * 16];
     const GemmProb* __restrict__ pp = probs + blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwave = blockDim.x >> 6;                           // 4: two workgroups (two leaves) share a CU, one's epilogue
@@ -572,25 +573,35 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
     double* const C = pp->C; const long ldc = pp->ldc;
     const int zc = pp->zc;
     const d4 zero = {0, 0, 0, 0};
-    for (int rg = 0; rg < ntm; rg += 2 * nwave) {
-        const int i0 = rg + wave, i1 = rg + wave + nwave;
-        const bool v0 = i0 < ntm, v1 = i1 < ntm;
-        const long row0 = (long)(v0 ? i0 : 0) * 16 + r, row1 = (long)(v1 ? i1 : 0) * 16 + r;
-        const double* a0p = A + row0 * lda + 4 * q;
-        const double* a1p = A + row1 * lda + 4 * q;
-        for (int j0 = 0; j0 < ntn; j0 += LG_CT) {
-            const int nc = min(LG_CT, ntn - j0);                 // column tiles of this pass
+    constexpr int NST = (CT * 64 + 255) / 256;                   // 32-byte staging chunks per thread (256 threads)
+    for (int rg = 0; rg < ntm; rg += RT * nwave) {
+        bool vr[RT];
+        long rowh[RT];
+        const double* ap[RT];
+#pragma unroll
+        for (int h = 0; h < RT; ++h) {
+            const int ih = rg + wave + h * nwave;
+            vr[h] = ih < ntm;
+            rowh[h] = (long)(vr[h] ? ih : 0) * 16 + r;
+            ap[h] = A + rowh[h] * lda + 4 * q;
+        }
+        for (int j0 = 0; j0 < ntn; j0 += CT) {
+            const int nc = min(CT, ntn - j0);                    // column tiles of this pass
             const int nchunk = nc * 64;                          // 32-byte chunks (row, 4 columns) of the staged nc*16 x 16 slab
-            // staging role: up to two chunks per thread
-            const int e0 = threadIdx.x, e1 = threadIdx.x + blockDim.x;
-            const bool on0 = e0 < nchunk, on1 = e1 < nchunk;
-            const int sr0 = e0 >> 2, sc0 = (e0 & 3) << 2, sr1 = e1 >> 2, sc1 = (e1 & 3) << 2;
-            long br0 = j0 * 16 + sr0, br1 = j0 * 16 + sr1;
-            bool ok0 = on0 && br0 < N, ok1 = on1 && br1 < N;
-            if (ok0 && idxB) { const int ib = gldi(idxB + br0); ok0 = ib >= 0; br0 = ib; }
-            if (ok1 && idxB) { const int ib = gldi(idxB + br1); ok1 = ib >= 0; br1 = ib; }
-            const double* bp0 = B + (ok0 ? br0 : 0) * ldb + sc0;
-            const double* bp1 = B + (ok1 ? br1 : 0) * ldb + sc1;
+            bool on[NST], ok[NST];
+            int so[NST];
+            const double* bp[NST];
+#pragma unroll
+            for (int g = 0; g < NST; ++g) {
+                const int e = threadIdx.x + g * 256;
+                on[g] = e < nchunk;
+                const int sr = e >> 2, sc = (e & 3) << 2;
+                so[g] = sr * LG_LD + sc;
+                long br = j0 * 16 + sr;
+                ok[g] = on[g] && br < N;
+                if (ok[g] && idxB) { const int ib = gldi(idxB + br); ok[g] = ib >= 0; br = ib; }
+                bp[g] = B + (ok[g] ? br : 0) * ldb + sc;
+            }
             __syncthreads();                                     // previous pass is done with sB / sXB / sIB
             if (EPI == EPI_COV || EPI == EPI_HOSTCOV) {
                 for (int t = threadIdx.x; t < nc * 16; t += blockDim.x) {
@@ -603,56 +614,64 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
                     }
                 }
             }
-            d4 acc0[LG_CT], acc1[LG_CT];
+            d4 acc[RT][CT];
 #pragma unroll
-            for (int j = 0; j < LG_CT; ++j) { acc0[j] = zero; acc1[j] = zero; }
+            for (int h = 0; h < RT; ++h)
+#pragma unroll
+                for (int j = 0; j < CT; ++j) acc[h][j] = zero;
             if (EPI == EPI_SUB) {
                 // the C tiles go straight into the accumulators (negated; the epilogue writes -acc = C_in - A B^T): their
                 // loads are in flight beside the first chunk and cost no registers
 #pragma unroll
-                for (int j = 0; j < LG_CT; ++j) {
+                for (int j = 0; j < CT; ++j) {
                     if (j < nc) {
                         const int col = (j0 + j) * 16 + 4 * q;
                         if (!(zc > 0 && col >= zc)) {
-                            if (v0) acc0[j] = -gld4(C + row0 * ldc + col);
-                            if (v1) acc1[j] = -gld4(C + row1 * ldc + col);
+#pragma unroll
+                            for (int h = 0; h < RT; ++h) if (vr[h]) acc[h][j] = -gld4(C + rowh[h] * ldc + col);
                         }
                     }
                 }
             }
-            d4 sb0 = zero, sb1 = zero, fa0 = zero, fa1 = zero;
-            if (nk > 0) { sb0 = gld4(bp0); sb1 = gld4(bp1); fa0 = gld4(a0p); fa1 = gld4(a1p); }
-            if (on0) *(d4*)(&sB[0][sr0 * LG_LD + sc0]) = ok0 ? sb0 : zero;
-            if (on1) *(d4*)(&sB[0][sr1 * LG_LD + sc1]) = ok1 ? sb1 : zero;
+            d4 sb[NST], fa[RT];
+#pragma unroll
+            for (int g = 0; g < NST; ++g) sb[g] = nk > 0 ? gld4(bp[g]) : zero;
+#pragma unroll
+            for (int h = 0; h < RT; ++h) fa[h] = nk > 0 ? gld4(ap[h]) : zero;
+#pragma unroll
+            for (int g = 0; g < NST; ++g) if (on[g]) *(d4*)(&sB[0][so[g]]) = ok[g] ? sb[g] : zero;
             __syncthreads();
             for (int ks = 0; ks < nk; ++ks) {
                 const int cur = ks & 1;
                 const int kn = (ks + 1 < nk ? ks + 1 : ks) * 16;
-                const d4 a0 = fa0, a1 = fa1;
-                sb0 = gld4(bp0 + kn); sb1 = gld4(bp1 + kn); fa0 = gld4(a0p + kn); fa1 = gld4(a1p + kn);   // next chunk in flight
+                d4 a[RT];
 #pragma unroll
-                for (int j = 0; j < LG_CT; ++j) {
+                for (int h = 0; h < RT; ++h) a[h] = fa[h];
+#pragma unroll
+                for (int g = 0; g < NST; ++g) sb[g] = gld4(bp[g] + kn);       // next chunk in flight during the products
+#pragma unroll
+                for (int h = 0; h < RT; ++h) fa[h] = gld4(ap[h] + kn);
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
                     if (j < nc) {
                         const d4 b = *(const d4*)(&sB[cur][(j * 16 + prow) * LG_LD + 4 * q]);
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            acc0[j] = mfma16(b[s4], a0[s4], acc0[j]);
-                            acc1[j] = mfma16(b[s4], a1[s4], acc1[j]);
-                        }
+                        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                            for (int h = 0; h < RT; ++h) acc[h][j] = mfma16(b[s4], a[h][s4], acc[h][j]);
                     }
                 }
                 if (ks + 1 < nk) {
-                    if (on0) *(d4*)(&sB[cur ^ 1][sr0 * LG_LD + sc0]) = ok0 ? sb0 : zero;
-                    if (on1) *(d4*)(&sB[cur ^ 1][sr1 * LG_LD + sc1]) = ok1 ? sb1 : zero;
+#pragma unroll
+                    for (int g = 0; g < NST; ++g) if (on[g]) *(d4*)(&sB[cur ^ 1][so[g]]) = ok[g] ? sb[g] : zero;
                     __syncthreads();
                 }
             }
             // ---- epilogue: lane (r,q) of tile (i,j) holds C[i*16 + r][j*16 + 4q .. 4q+3]
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool vh = h ? v1 : v0;
-                if (!vh) continue;
-                const long row = h ? row1 : row0;
+            for (int h = 0; h < RT; ++h) {
+                if (!vr[h]) continue;
+                const long row = rowh[h];
                 double xa[DIM];
                 int op = -1;
                 if (EPI == EPI_COV) {
@@ -661,14 +680,14 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
                 }
                 if (EPI == EPI_COV || EPI == EPI_HOSTCOV) op = pp->rowmap ? gldi(pp->rowmap + row) : -1;
 #pragma unroll
-                for (int j = 0; j < LG_CT; ++j) {
+                for (int j = 0; j < CT; ++j) {
                     if (j < nc) {
-                        const d4 acc = h ? acc1[j] : acc0[j];
+                        const d4 ac = acc[h][j];
                         const int col = (j0 + j) * 16 + 4 * q;
                         double* cp = C + row * ldc + col;
                         d4 v;
-                        if (EPI == EPI_SET) v = acc;
-                        else if (EPI == EPI_SUB) v = -acc;
+                        if (EPI == EPI_SET) v = ac;
+                        else if (EPI == EPI_SUB) v = -ac;
                         else {
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
                                 double cv;
                                 if (EPI == EPI_COV) cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, &sXB[lc * DIM], kp.circular));
                                 else cv = gld(pp->Csrc + row * pp->ldcs + col + s4);
-                                v[s4] = ib < 0 ? 0.0 : cv - acc[s4];
+                                v[s4] = ib < 0 ? 0.0 : cv - ac[s4];
                             }
                             if (op >= 0) {
                                 d4 v2 = v;

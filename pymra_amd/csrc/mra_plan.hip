@@ -88,7 +88,7 @@ static const char* kfam_name[2][KF_COUNT] = {
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
      "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)",
-     "k_leaf_gemm<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
      "k_front (assembly + partial Cholesky + Schur per level)",
      "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)",
      "k_trsm_rows2 predict (unused on the fused path)",
@@ -100,7 +100,7 @@ static const char* kfam_name[2][KF_COUNT] = {
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
      "k_gemm_nt<SET> / k_parent_front leaf or parent SYRK",
-     "k_leaf_gemm<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
      "k_front / k_panel_chol front partial Cholesky",
      "k_gemm_nt<SUB> front Schur complement",
      "k_trsm_rows2 predict X = W Lt^-T per level",
@@ -223,7 +223,7 @@ struct mra_plan {
     int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
     double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
     // fused ("regular tree") path
-    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true;
+    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true, leaf_gemm_update = false;
     int dbg = 0;
     int NL = 0, CWT = 0;
     struct FusedLevel {
@@ -846,17 +846,22 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
     }
 }
 
-// leaf-resident product (one workgroup per problem): the two big leaf GEMMs of a pass
+// leaf-resident product (one workgroup per problem): the two big leaf GEMMs of a pass.  The residual (few column tiles, long K)
+// runs two row tiles per wave, the update (13 column tiles at C3, short K) one row tile per wave with all columns in one pass.
 template <int EPI>
 static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) {
     if (!nprob) return;
     const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
     const dim3 grid((unsigned)nprob), block(256);
-#define MRA_LG_LAUNCH(D, MD) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, block, 0, pl->stream, probs, pl->kp)
+    constexpr int RT = (EPI == EPI_SUB) ? 1 : 2, CT = (EPI == EPI_SUB) ? 13 : 7;
+#define MRA_LG_LAUNCH(D, MD) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), RT, CT>), grid, block, 0, pl->stream, probs, pl->kp)
     if (pl->d == 1) { if (mode == 0) MRA_LG_LAUNCH(1, 0); else if (mode == 1) MRA_LG_LAUNCH(1, 1); else if (mode == 2) MRA_LG_LAUNCH(1, 2); else MRA_LG_LAUNCH(1, 3); }
     else { if (mode == 0) MRA_LG_LAUNCH(2, 0); else if (mode == 1) MRA_LG_LAUNCH(2, 1); else if (mode == 2) MRA_LG_LAUNCH(2, 2); else MRA_LG_LAUNCH(2, 3); }
 #undef MRA_LG_LAUNCH
 }
+// the leaf-resident kernel pays off for leaves with many rows and a K loop of at least a few chunks; small leaves (config 5:
+// 64 rows, 32 observations) keep the 64x64-tile kernel
+static bool leaf_gemm_ok(const mra_plan* pl) { return pl->use_leaf_gemm && pl->leaf_max_rows >= 128 && pl->leaf_max_nop >= 64; }
 
 static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob) {
     if (!nprob) return;
@@ -1327,11 +1332,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         {
             KTimer kt(pl, KF_LEAF_RESID, c_only ? 0.0 : pl->fl_leaf_resid);
             if (pl->host_cov) {
-                if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl);
+                if (leaf_gemm_ok(pl)) launch_leaf_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl);
                 else launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
             }
             else if (c_only) launch_gemm<EPI_COV>(pl, pl->gLeafResidLik.p, nl, pl->leaf_max_nop, pl->leaf_max_nop);
-            else if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl);
+            else if (leaf_gemm_ok(pl)) launch_leaf_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl);
             else launch_gemm<EPI_COV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
         }
         if (pl->leaf_max_nop > 0) {
@@ -1403,7 +1408,9 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             }
             {
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
-                if (pl->use_leaf_gemm) launch_leaf_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl);
+                // (measured: the leaf-resident form wins for the residual - 1.07 vs 1.15 ms at C3 - but not for the update,
+                // 1.34-1.39 vs 1.29 ms, whatever the pass structure; MRA_OPT_LEAF_GEMM = 2 selects it for A/B runs)
+                if (leaf_gemm_ok(pl) && pl->leaf_gemm_update) launch_leaf_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl);
                 else launch_gemm<EPI_SUB>(pl, pl->gLeafUpdate.p, nl, pl->leaf_max_rows, pl->leaf_max_na);
             }
             if (side) {
@@ -1733,7 +1740,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
     if (option == 4) { pl->use_front_fused = value != 0; return MRA_OK; }
     if (option == 5) { pl->use_knot_chain = value != 0; return MRA_OK; }
-    if (option == 6) { pl->use_leaf_gemm = value != 0; return MRA_OK; }
+    if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
     if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }
