@@ -16,6 +16,11 @@ pymra_amd/libmra_hip_asan.so: $(DEPS)
 	$(HIPCC) $(FLAGS) -O1 -g -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer \
 	    -Xarch_host -fno-sanitize-recover=undefined -o $@ $(SRC) -ldl
 
+# Diagnostic build with in-kernel clock stamps in the prior row cascade (tools/stamps_cascade.py); never the product.
+stamps: pymra_amd/libmra_hip_stamps.so
+pymra_amd/libmra_hip_stamps.so: $(DEPS)
+	$(HIPCC) $(FLAGS) -O3 -DMRA_STAMPS -o $@ $(SRC) -ldl
+
 clean:
-	rm -f pymra_amd/libmra_hip.so pymra_amd/libmra_hip_asan.so
-.PHONY: lib asan clean
+	rm -f pymra_amd/libmra_hip.so pymra_amd/libmra_hip_asan.so pymra_amd/libmra_hip_stamps.so
+.PHONY: lib asan stamps clean

@@ -1226,6 +1226,7 @@ struct CascadeArgs {
     double* Lp_out;           // [node][cw][cw]
     double* invd_out;         // [node][cwt][256]
     int* err;
+    unsigned long long* stamps;   // diagnostic build (-DMRA_STAMPS) only: 16 s_memtime stamps per row tile
     int dbg;                  // what-if timing switches (results are wrong when set): 1 no Ut scatter, 2 no W stores, 4 constant instead of kernel evaluation
     int node_base;            // KNOT: node number of slot 0 of the level being factorised (error reports name node + 1)
 };
@@ -1393,6 +1394,13 @@ __device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, in
     return ssq;
 }
 
+// In-kernel stamps (cdna_hip_programming.md section 7): a diagnostic build records the shader clock at the phase boundaries
+// of every row tile into a buffer of its own; the product build compiles none of it.
+#ifdef MRA_STAMPS
+#define MRA_STAMP(slot) do { if (ar.stamps && !ar.knot_mode && lane == 0) ar.stamps[(t) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MRA_STAMP(slot) do { } while (0)
+#endif
 // One workgroup = the row tiles of one leaf (FULL) or the knot tiles of one node (KNOT): they share
 // the same node on every level.  STAGE_ALL: the operands of ALL levels (Wk, strictly-lower tiles of L,
 // inverted diagonal blocks) are staged in LDS once, then every wave walks its tiles down the levels
@@ -1408,12 +1416,19 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
     const int prow = pi16(r);
     const int* chain = ar.tile_chain + t0 * 8;          // identical for every tile of the workgroup
     if (STAGE_ALL) {
+#ifdef MRA_STAMPS
+        const unsigned long long t_wg0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int m = 0; m < NLMAX; ++m)
             if (m <= ar.mlast) cascade_stage_level<CWT>(ar, m, chain[m], lds + cascade_level_off<CWT>(m) * 256);
         __syncthreads();
         for (int tw = wave; tw < nt_wg; tw += nwave) {
             const long t = t0 + tw;
+#ifdef MRA_STAMPS
+            if (ar.stamps && !ar.knot_mode && lane == 0) ar.stamps[t * 16 + 0] = t_wg0;
+#endif
+            MRA_STAMP(1);
             long myrow;
             bool phantom_row = false;
             if (ar.knot_mode) {
@@ -1433,9 +1448,12 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             for (int m = 0; m < NLMAX; ++m)
                 if (m <= ar.mlast) {
                     cascade_compute_level<CWT, NLMAX, DIM, MODE>(ar, kp, m, chain[m], lds + cascade_level_off<CWT>(m) * 256, w, xr, prow, q);
+                    MRA_STAMP(2 + 2 * m);
                     if (!ar.knot_mode) ssq += cascade_output_level<CWT, NLMAX>(ar, m, t, myrow, op, w, q);
+                    MRA_STAMP(3 + 2 * m);
                 }
             cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
+            MRA_STAMP(15);
         }
     } else {
         const bool active = wave < nt_wg;

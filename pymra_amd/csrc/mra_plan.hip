@@ -183,7 +183,7 @@ struct mra_plan {
     double R = 0.0;
     int reduce_level = -1;
     // device data
-    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag;
+    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps;
     double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
     double* host_res_dev = nullptr;  // the same memory as the device sees it
     DevVec<int> errflag, knot_idx, row_leaf;
@@ -1005,6 +1005,10 @@ static void run_prior_fused(mra_plan* pl) {
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.dbg = pl->dbg;
+#ifdef MRA_STAMPS
+        if (!pl->stamps.p) { pl->stamps.alloc((size_t)pl->n_ftiles * 16); HIP_TRY(mraMemset(pl->stamps.p, 0, pl->stamps.n * sizeof(double))); }
+        ar.stamps = (unsigned long long*)pl->stamps.p;
+#endif
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
         ar.ycol = pl->Ka; ar.y = pl->y.p;
         if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
@@ -1686,6 +1690,7 @@ int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_
         const double* src = nullptr; int64_t n = 0;
         if (what == 0) { src = pl->W.p; n = (int64_t)pl->W.n; }
         else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
+        else if (what == 2) { src = pl->stamps.p; n = (int64_t)pl->stamps.n; }     // -DMRA_STAMPS builds: raw 64-bit clock stamps
         else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
         *n_avail = n;
         if (out && cap > 0) HIP_TRY(mraMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
