@@ -832,7 +832,7 @@ struct PanelProb {
 };
 
 __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restrict__ probs,
-                                                     double* __restrict__ dnode, int* __restrict__ err) {
+                                                     double* __restrict__ dnode, int* __restrict__ err, int accumulate = 0) {
     const PanelProb pb = probs[blockIdx.x];
     __shared__ __attribute__((aligned(16))) double sd[16][17];
     __shared__ double sinv[16][17];
@@ -901,7 +901,8 @@ __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restri
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) dnode[pb.node] = 2.0 * logacc;
+    // accumulate: a later 64-column step of a blocked factorisation (large leaves) adds its share of the log-determinant
+    if (threadIdx.x == 0) dnode[pb.node] = (accumulate ? dnode[pb.node] : 0.0) + 2.0 * logacc;
 }
 
 // ------------------------------------------------------------------------------------------------

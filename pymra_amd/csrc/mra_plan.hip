@@ -204,6 +204,11 @@ struct mra_plan {
     std::vector<GemmProb> hLeafResid;
     std::vector<int> leaf_nobs_host;
     DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
+    // leaves with more than 192 observations: right-looking blocked factorisation, 64 columns per step (one panel launch +
+    // one trailing-update GEMM per step); [variant 0 full / 1 likelihood-only][step] -> descriptors of all leaves
+    std::vector<DevVec<PanelProb>> gBigPanel[2];
+    std::vector<DevVec<GemmProb>> gBigTrail[2];
+    std::vector<long> bigM[2], bigN[2];
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
     size_t n_trsm_small = 0;            // the *Plain arrays are ordered: leaves with nt <= 8 first
     int trsm_small_nt = 0, trsm_small_tiles_full = 0, trsm_small_tiles_lik = 0;
@@ -771,6 +776,45 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->gLeafResidLik.upload(grl);
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
+    for (int v = 0; v < 2; ++v) { pl->gBigPanel[v].clear(); pl->gBigTrail[v].clear(); pl->bigM[v].clear(); pl->bigN[v].clear(); }
+    if (pl->leaf_max_nop / 16 > 12) {
+        const int NBT = 4;                                        // column tiles per step
+        const int nsteps = (pl->leaf_max_nop / 16 + NBT - 1) / NBT;
+        for (int v = 0; v < 2; ++v) {
+            pl->gBigPanel[v].resize(nsteps); pl->gBigTrail[v].resize(nsteps);
+            pl->bigM[v].assign(nsteps, 0); pl->bigN[v].assign(nsteps, 0);
+            for (int st = 0; st < nsteps; ++st) {
+                std::vector<PanelProb> pp(nl);
+                std::vector<GemmProb> gg(nl);
+                for (size_t t = 0; t < nl; ++t) {
+                    const PanelProb& full = v == 0 ? pf[t] : pk[t];
+                    const int ntl = full.ne, c0 = st * NBT;               // column tiles of this leaf, first tile of the step
+                    const int ne = std::max(0, std::min(NBT, ntl - c0));
+                    const long nop = full.ld;
+                    PanelProb q = full;
+                    q.P = full.P + (size_t)c0 * 16 * nop + (size_t)c0 * 16;
+                    q.invd = full.invd + (size_t)c0 * 256;
+                    q.ht = ne > 0 ? full.ht - c0 : 0;
+                    q.ne = ne;
+                    pp[t] = q;
+                    GemmProb g{};
+                    const int c1 = c0 + ne;
+                    g.M = ne > 0 ? (full.ht - c1) * 16 : 0;
+                    g.N = ne > 0 ? (ntl - c1) * 16 : 0;
+                    if (g.N <= 0 || g.M <= 0) { g.M = 0; g.N = 0; }
+                    g.K = ne * 16;
+                    g.A = full.P + (size_t)c1 * 16 * nop + (size_t)c0 * 16; g.lda = nop;
+                    g.B = g.A; g.ldb = nop;
+                    g.C = full.P + (size_t)c1 * 16 * nop + (size_t)c1 * 16; g.ldc = nop;
+                    gg[t] = g;
+                    pl->bigM[v][st] = std::max<long>(pl->bigM[v][st], g.M);
+                    pl->bigN[v][st] = std::max<long>(pl->bigN[v][st], g.N);
+                }
+                pl->gBigPanel[v][st].upload(pp);
+                pl->gBigTrail[v][st].upload(gg);
+            }
+        }
+    }
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
     for (auto& e : tf) e.gtiles = 0;
     for (auto& e : tk) e.gtiles = 0;
@@ -863,9 +907,9 @@ static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) 
 // 64 rows, 32 observations) keep the 64x64-tile kernel
 static bool leaf_gemm_ok(const mra_plan* pl) { return pl->use_leaf_gemm && pl->leaf_max_rows >= 128 && pl->leaf_max_nop >= 64; }
 
-static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob) {
+static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob, int accumulate = 0) {
     if (!nprob) return;
-    hipLaunchKernelGGL(k_panel_chol, dim3((unsigned)nprob), dim3(256), 0, pl->stream, probs, pl->dnode.p, pl->errflag.p);
+    hipLaunchKernelGGL(k_panel_chol, dim3((unsigned)nprob), dim3(256), 0, pl->stream, probs, pl->dnode.p, pl->errflag.p, accumulate);
 }
 
 // row-tile triangular solve with L in LDS; returns false when nt is too large for the LDS path
@@ -1373,7 +1417,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 }
                 else launch_trsm2(pl, pred ? pl->gLeafTrsmFull.p : pl->gLeafTrsmLik.p, nl, ntl, mt, mt);
             } else {
-                launch_panel(pl, pred ? pl->gLeafCholFull.p : pl->gLeafCholLik.p, nl);
+                // right-looking, 64 columns per step: the panel (factor + solve of ALL rows below, Ut and Tt included) on one
+                // workgroup per leaf, the rank-64 update of everything to its right as a batched GEMM over the whole GPU
+                // (a single workgroup factorising an 8560 x 8560 block column by column took 15 s: README example 1)
+                const int v = pred ? 0 : 1;
+                for (size_t st = 0; st < pl->gBigPanel[v].size(); ++st) {
+                    launch_panel(pl, pl->gBigPanel[v][st].p, nl, st > 0 ? 1 : 0);
+                    if (pl->bigM[v][st] > 0 && pl->bigN[v][st] > 0)
+                        launch_gemm<EPI_SUB>(pl, pl->gBigTrail[v][st].p, nl, pl->bigM[v][st], pl->bigN[v][st]);
+                }
             }
         }
         pl->direct_parent = pl->parent_syrk && pl->reduce_level != pl->NL - 1;

@@ -105,3 +105,23 @@ def test_readme_example_1_small(built_library):
     assert np.max(np.abs(np.asarray(yP).ravel() - mean)) < 1e-8 and K.rel(sdP, sd) < 1e-7
     assert abs(float(mraTree.getLikelihood()[0, 0]) - lik) <= 1e-9 * abs(lik)
     assert sdP.reshape((Nx, Ny)).shape == (10, 10) and yP.reshape((Nx, Ny)).shape == (10, 10)
+
+
+def test_readme_example_1_on_a_large_single_leaf(built_library):
+    """README example 1 on a 40 x 40 sub-grid of the packaged 100 x 100 sample: M = 0 puts all 1600 points (about 1370
+    observed: 86 column tiles) into ONE leaf, the blocked right-looking Cholesky path for large leaves, against exact
+    kriging.  (The full 100 x 100 case is the same code with 535 column tiles; tools/readme_example1.py times it.)"""
+    import pymra_amd.DataLoader as dl
+    import pymra_amd.MRATools as mt
+    from pymra_amd import MRATree
+    y, locs, y_obs = dl.load_data("large", True)
+    n = 40
+    sel = np.array([j * 100 + i for j in range(n) for i in range(n)])
+    locs, y_obs = locs[sel], y_obs[sel].reshape(-1, 1)
+    tree = MRATree(locs, 4, lambda a, b: mt.ExpCovFun(a, b, l=2), y_obs, 1e-4, 0)
+    assert tree.M == 0 and tree.topology.n_nodes == 1
+    yP, sdP = tree.predict()
+    lik, mean, sd = K.kriging(locs, y_obs, mt.KernelSpec(mt.KIND_EXP, 2.0), 1e-4)
+    assert abs(float(tree.getLikelihood()[0, 0]) - lik) <= 1e-8 * abs(lik)
+    assert np.max(np.abs(np.asarray(yP).ravel() - mean)) < 1e-6
+    assert K.rel(sdP, sd) < 1e-5                              # cond(Sigma_y) ~ 1e8 at me_scale = 1e-4: both sides lose digits
