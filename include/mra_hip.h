@@ -164,6 +164,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_KNOT_CHAIN     5   /* 1 (default): knot pass of all levels in one launch (k_knot_chain); 0: one launch per level */
 #define MRA_OPT_LEAF_GEMM      6   /* 1 (default): leaf-resident residual product (k_leaf_gemm, one workgroup per leaf); 2: also the leaf
                                       update; 0: 64x64-tile k_gemm_nt_lds for both */
+#define MRA_OPT_LEAF_SOLVE     7   /* row solve Tt = V Lc^-T and leaf update in one launch (k_leaf_solve_update, Tt stays in registers):
+                                      2 (default) when a CU sees at most four leaves (sharded runs), 1 always, 0 never */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 int mra_kernel_family_count(void);

@@ -1173,6 +1173,168 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+//  Leaf solve + update in one launch:  Tt = V[S,o] Lc^-T  (row TRSM, as k_trsm_rows2),  var -= rowsumsq(Tt),
+//  W[S, anc | y] -= Tt Ut^T  (as k_leaf_gemm<SUB>)  - with Tt never written to memory: the solved tiles of a row tile stay
+//  in registers and ARE the A fragments of the update product.  Separately the two steps move 3.4 + 4.4 GB at C3 (both
+//  HBM-bound at 3.4-4.3 TB/s); fused, V is read once and W read and written once (MRANode.py:489-495, 510-511).
+//  One workgroup (8 waves) per leaf: Lc (strictly-lower tiles + inverted diagonal blocks) is staged in LDS once, each wave
+//  owns one 16-row tile per row group; Ut streams through a double-buffered LDS stage, 16 observations at a time, shared by
+//  the 8 waves (52 MFMAs per wave and barrier at C3).  The rows of Ut themselves are solved beforehand by k_trsm_rows2.
+// ------------------------------------------------------------------------------------------------
+struct LeafSolveProb {
+    const double* L;      // nt*16 square lower factor of C (row-major, ldL)
+    const double* invd;   // nt inverted diagonal blocks (256 doubles each)
+    const double* V;      // nrt row tiles of V[S,o] (row-major, ldx)
+    const double* Ut;     // nat*16 rows (ancestors + y), solved (row-major, ldx)
+    double* Wr;           // the leaf's rows of W at the first ancestor column (ldw)
+    double* var;          // per-row variance of the leaf's rows
+    long ldL, ldx, ldw;
+    int nt;               // column tiles of Lc = 16-observation chunks
+    int nrt;              // row tiles
+    int nat;              // column tiles of the update (ancestors + y block)
+    int zt;               // column tiles >= zt take C_in = 0 (the y block)
+};
+
+// LLDS = true: Lc staged in LDS, one 8-wave workgroup per CU.  (LLDS = false - Lc read through L1/L2, two 4-wave workgroups
+// per CU - was measured: 300 B/lane of spills and exposed L2 latency in the solve, 15 % slower over the whole pass; not launched.)
+template <int NTMAX, int CT, bool LLDS>
+__global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_update(const LeafSolveProb* __restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NTHR = LLDS ? 512 : 256;
+    constexpr int NWAVE = NTHR / 64;
+    constexpr int NST = (CT * 64 + NTHR - 1) / NTHR;            // 32-byte Ut staging pieces per thread
+    const LeafSolveProb* __restrict__ pp = probs + blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int prow = pi16(r);
+    const int nt = pp->nt, nrt = pp->nrt, nat = pp->nat, zt = pp->zt;
+    const int ntri = nt * (nt - 1) / 2;
+    const long ldx = pp->ldx, ldw = pp->ldw, ldL = pp->ldL;
+    const double* const Lg = pp->L;
+    const double* const invg = pp->invd;
+    const d4 zero = {0, 0, 0, 0};
+    double* const sL = lds;                                     // LLDS: (ntri + nt) tiles, FT_SZ doubles each
+    double* const sU0 = lds + (LLDS ? (long)(ntri + nt) * FT_SZ : 0);        // two stages of nat*16 rows x LG_LD
+    double* const sU1 = sU0 + (long)nat * 16 * LG_LD;
+    if (LLDS) {
+        // ---- stage Lc: 16-byte chunks, eight in flight per thread
+        const int total = (ntri + nt) * 128;
+        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * NTHR) {
+            d2 v[8];
+            int dst[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                int e = e0 + g * NTHR;
+                e = e < total ? e : total - 1;
+                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
+                const double* src;
+                if (tile < ntri) {
+                    int jb = 1;
+                    while ((jb + 1) * jb / 2 <= tile) ++jb;
+                    const int kb = tile - jb * (jb - 1) / 2;
+                    src = Lg + (long)(jb * 16 + row) * ldL + kb * 16 + c2;
+                } else src = invg + (long)(tile - ntri) * 256 + row * 16 + c2;
+                v[g] = gld2(src);
+                dst[g] = tile * FT_SZ + row * FT_LD + c2;
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) if (e0 + g * NTHR < total) *(d2*)(sL + dst[g]) = v[g];
+        }
+    }
+    // staging role for Ut chunks: 32-byte pieces (row, 4 columns) of the nat*16 x 16 slab
+    const int nch = nat * 64;
+    bool on[NST];
+    int so[NST];
+    const double* up[NST];
+#pragma unroll
+    for (int g = 0; g < NST; ++g) {
+        const int e = threadIdx.x + g * NTHR;
+        on[g] = e < nch;
+        so[g] = (e >> 2) * LG_LD + ((e & 3) << 2);
+        up[g] = pp->Ut + (long)(on[g] ? e >> 2 : 0) * ldx + ((e & 3) << 2);
+    }
+    __syncthreads();
+    for (int rg = 0; rg < nrt; rg += NWAVE) {
+        const int t = rg + wave;
+        const bool valid = t < nrt;
+        const long row = (long)(valid ? t : 0) * 16 + r;
+        // ---- Tt tile: x = V L^-T in registers (vec layout), var -= |x|^2
+        d4 x[NTMAX];
+        {
+            const double* vp = pp->V + row * ldx + 4 * q;
+#pragma unroll
+            for (int jb = 0; jb < NTMAX; ++jb) x[jb] = (jb < nt) ? gld4(vp + jb * 16) : zero;
+        }
+        // first Ut chunk in flight beside the solve
+        d4 sg[NST];
+#pragma unroll
+        for (int g = 0; g < NST; ++g) sg[g] = gld4(up[g]);
+        double ssq = 0.0;
+#pragma unroll
+        for (int jb = 0; jb < NTMAX; ++jb) {
+            if (jb < nt) {
+                d4 acc = x[jb];
+                d4 u0 = zero, u1 = zero;
+#pragma unroll
+                for (int kb = 0; kb < jb; ++kb) {
+                    const d4 a = LLDS ? *(const d4*)(sL + (long)(jb * (jb - 1) / 2 + kb) * FT_SZ + prow * FT_LD + 4 * q)
+                                      : gld4(Lg + (long)(jb * 16 + prow) * ldL + kb * 16 + 4 * q);
+                    u0 = mfma16(a[0], x[kb][0], u0); u1 = mfma16(a[1], x[kb][1], u1);
+                    u0 = mfma16(a[2], x[kb][2], u0); u1 = mfma16(a[3], x[kb][3], u1);
+                }
+                if (jb > 0) acc -= u0 + u1;
+                const d4 ia = LLDS ? *(const d4*)(sL + (long)(ntri + jb) * FT_SZ + prow * FT_LD + 4 * q)
+                                   : gld4(invg + (long)jb * 256 + prow * 16 + 4 * q);
+                d4 y0 = mfma16(ia[0], acc[0], zero), y1 = mfma16(ia[1], acc[1], zero);
+                y0 = mfma16(ia[2], acc[2], y0); y1 = mfma16(ia[3], acc[3], y1);
+                const d4 xx = y0 + y1;
+                x[jb] = xx;
+                ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
+            }
+        }
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (valid && q == 0) { double* vp = pp->var + row; gst(vp, gld(vp) - ssq); }
+        // ---- update accumulators start from -W (the epilogue writes -acc = W - Tt Ut^T)
+        d4 acc[CT];
+        double* wp = pp->Wr + row * ldw + 4 * q;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = (valid && j < nat && j < zt) ? -gld4(wp + j * 16) : zero;
+        __syncthreads();                                        // the previous row group is done with the stages
+#pragma unroll
+        for (int g = 0; g < NST; ++g) if (on[g]) *(d4*)(sU0 + so[g]) = sg[g];
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NTMAX; ++kb) {
+            if (kb < nt) {
+                const double* st = (kb & 1) ? sU1 : sU0;
+                const int kn = (kb + 1 < nt ? kb + 1 : kb) * 16;
+#pragma unroll
+                for (int g = 0; g < NST; ++g) sg[g] = gld4(up[g] + kn);
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    if (j < nat) {
+                        const d4 b = *(const d4*)(st + (j * 16 + prow) * LG_LD + 4 * q);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) acc[j] = mfma16(b[s4], x[kb][s4], acc[j]);
+                    }
+                }
+                if (kb + 1 < nt) {
+                    double* sn = (kb & 1) ? sU0 : sU1;
+#pragma unroll
+                    for (int g = 0; g < NST; ++g) if (on[g]) *(d4*)(sn + so[g]) = sg[g];
+                    __syncthreads();
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) if (j < nat) gst4(wp + j * 16, -acc[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 //  Fused prior cascade ("regular" trees: every non-leaf level has the same knot-block width
 //  CWT*16 and all leaves sit on the last level).
 //

@@ -210,6 +210,11 @@ struct mra_plan {
     std::vector<DevVec<GemmProb>> gBigTrail[2];
     std::vector<long> bigM[2], bigN[2];
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
+    DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
+    DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
+    bool use_leaf_solve = true, leaf_solve_ok = false;
+    size_t leaf_solve_lds = 0;
+    int leaf_solve_mode = 2;              // MRA_OPT_LEAF_SOLVE: 0 off, 1 always, 2 (default) when the leaves are few per CU
     size_t n_trsm_small = 0;            // the *Plain arrays are ordered: leaves with nt <= 8 first
     int trsm_small_nt = 0, trsm_small_tiles_full = 0, trsm_small_tiles_lik = 0;
     DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
@@ -246,6 +251,7 @@ struct mra_plan {
     size_t cascade_lds = 0, cascade_lds_all = 0;
     bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
     bool cascade_group_siblings = false;
+    int n_cu = 256;
     // knot pass of all levels in one launch (k_knot_chain)
     bool use_knot_chain = true, knot_chain_ok = false;
     int kc_levels = 0;                    // levels 0 .. kc_levels-1 go through the chain kernel
@@ -570,6 +576,7 @@ static void build_static(mra_plan* pl) {
                 hipDeviceProp_t prop;
                 if (!g_dry && hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
             }
+            pl->n_cu = ncu;
             int nlv = 1;
             while (nlv < pl->NL && (long)pl->lev[nlv].nodes.size() <= ncu) ++nlv;
             pl->kc_levels = nlv;
@@ -837,6 +844,36 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->n_trsm_small = 0;
         for (size_t t = 0; t < nl; ++t) if (tf[t].nt <= 8) ++pl->n_trsm_small;
         pl->gLeafTrsmFullPlain.upload(tf2); pl->gLeafTrsmLikPlain.upload(tk2);
+        {
+            // fused row solve + update (k_leaf_solve_update) for the leaves with at most 8 observation tiles, in the same order
+            std::vector<LeafSolveProb> sp;
+            std::vector<GemmProb> up;
+            int nat_max = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (size_t t = 0; t < nl; ++t) {
+                    const bool small = tf[t].nt <= 8;
+                    if (small != (pass == 0)) continue;
+                    const int i = pl->leaf_nodes[t];
+                    const int m = pl->node_level[i];
+                    const int na = pl->na[m], a0 = pl->asuf[m], nop = pl->leaf_nop[t];
+                    const long r0 = pl->row0[i], nr = pl->row1[i] - r0;
+                    double* Pn = pl->panel.p + pl->leaf_poff[t];
+                    LeafSolveProb q{};
+                    q.L = Pn; q.invd = pl->leafInv.p + pl->leaf_ioff[t];
+                    q.V = Pn + (size_t)(nop + na) * nop; q.Ut = Pn + (size_t)nop * nop;
+                    q.Wr = pl->W.p + r0 * pl->ldw + a0; q.var = pl->var.p + r0;
+                    q.ldL = nop; q.ldx = nop; q.ldw = pl->ldw;
+                    q.nt = nop / 16; q.nrt = (int)(nr / 16); q.nat = na / 16; q.zt = (na - MRA_YB) / 16;
+                    sp.push_back(q);
+                    up.push_back(gu[t]);
+                    if (small) nat_max = std::max(nat_max, q.nat);
+                }
+            pl->gLeafSolve.upload(sp);
+            pl->gLeafUpdatePlain.upload(up);
+            const int nts = pl->trsm_small_nt;
+            pl->leaf_solve_lds = (size_t)((nts * (nts - 1) / 2 + nts) * FT_SZ + 2 * nat_max * 16 * LG_LD) * sizeof(double);
+            pl->leaf_solve_ok = pl->n_trsm_small > 0 && nat_max <= 13 && nat_max > 0 && pl->leaf_solve_lds <= 160 * 1024 && pl->leaf_max_rows >= 128;
+        }
     }
 }
 
@@ -1400,6 +1437,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 hipLaunchKernelGGL(k_leaf_fill, grid, dim3(256), 0, pl->stream, pl->gLeaf.p, pl->W.p, (long)pl->ldw, pl->R);
             }
         }
+        bool solve_fused = false;
         {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
             const int ntl = pl->leaf_max_nop / 16;
@@ -1407,10 +1445,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
                 if (fused) {
+                    // with the fused row solve + update the small leaves only need their Ut rows solved here
+                    // (one 8-wave workgroup per CU: a gain when a CU sees few leaves - 1.20 -> 1.14 ms on an eighth of C3, 1.97 -> 1.92
+                    // on a quarter - and neutral at sixteen per CU, where the separate kernels overlap better)
+                    solve_fused = pred && pl->use_leaf_solve && pl->leaf_solve_ok &&
+                                  (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(4 * pl->n_cu));
                     const Trsm2Prob* base = pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p;
                     const size_t ns = pl->n_trsm_small;
-                    const int mts = pred ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
-                    if (ns) launch_trsm2(pl, base, ns, pl->trsm_small_nt, mts, mts);
+                    const int mts = (pred && !solve_fused) ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
+                    if (ns) launch_trsm2(pl, solve_fused ? pl->gLeafTrsmLikPlain.p : base, ns, pl->trsm_small_nt, mts, mts);
                     // the few leaves with more than 128 observations: several workgroups per leaf when they are few
                     // (one leaf per workgroup would put a single 65 us workgroup on the critical path)
                     if (nl > ns) launch_trsm2(pl, base + ns, nl - ns, ntl, mt, (nl - ns) < 512 ? 4 : mt);
@@ -1462,7 +1505,19 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                                    pl->row_leaf.p, pl->W.p, (long)pl->ldw, pl->Ka, pl->var.p, cov0,
                                    pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
             }
-            {
+            if (solve_fused) {
+                // Tt = V Lc^-T, var -= |Tt|^2 and W -= Tt Ut^T in one launch for the leaves with <= 8 observation tiles; the few
+                // larger ones went through the full row solve above and take the plain update product
+                static bool attr = false;
+                if (!attr) {
+                    hipFuncSetAttribute((const void*)k_leaf_solve_update<8, 13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr = true;
+                }
+                KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
+                const size_t ns = pl->n_trsm_small;
+                hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p);
+                if (nl > ns) launch_gemm<EPI_SUB>(pl, pl->gLeafUpdatePlain.p + ns, nl - ns, pl->leaf_max_rows, pl->leaf_max_na);
+            } else {
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
                 // (measured: the leaf-resident form wins for the residual - 1.07 vs 1.15 ms at C3 - but not for the update,
                 // 1.34-1.39 vs 1.29 ms, whatever the pass structure; MRA_OPT_LEAF_GEMM = 2 selects it for A/B runs)
@@ -1798,6 +1853,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 4) { pl->use_front_fused = value != 0; return MRA_OK; }
     if (option == 5) { pl->use_knot_chain = value != 0; return MRA_OK; }
     if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
+    if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
     if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }

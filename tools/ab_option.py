@@ -18,13 +18,14 @@ if red >= 0: pl.set_reduce_level(red)
 def step():
     if red < 0: pl.run(True, True)
     else: pl.run(True, True, split=True); pl.resume()
-res = {0: [], 1: []}
+VALS = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0]
+res = {v: [] for v in VALS}
 for rnd in range(6):
-    for v in (1, 0):
+    for v in VALS:
         pl.set_option(opt, v)
         for _ in range(3): step()
         t0 = time.perf_counter()
         for _ in range(20): step()
         res[v].append((time.perf_counter() - t0) / 20 * 1e3)
-for v in (1, 0):
+for v in VALS:
     print("option %d = %d: median %.3f ms  min %.3f ms  (%s)" % (opt, v, float(np.median(res[v])), min(res[v]), " ".join("%.3f" % x for x in res[v])))
