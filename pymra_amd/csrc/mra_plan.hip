@@ -88,11 +88,11 @@ static const char* kfam_name[2][KF_COUNT] = {
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
      "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)",
-     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_gemm_nt_lds<SUB> / k_leaf_solve_update leaf update (separate launch)",
      "k_front (assembly + partial Cholesky + Schur per level)",
      "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)",
      "k_trsm_rows2 predict (unused on the fused path)",
-     "k_predict_cascade (all levels, mean/var)",
+     "k_predict_cascade (leaf update + all levels, mean/var)",
      "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"},
     {"k_gemm_nt_lds<COV> prior residual per level",
      "k_panel_chol prior kInv Cholesky per level",
@@ -213,6 +213,9 @@ struct mra_plan {
     DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
     DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
     bool use_leaf_solve = true, leaf_solve_ok = false;
+    bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
+    DevVec<long> leaf_row0_dev;
+    DevVec<unsigned char> leaf_upd_dev;
     size_t leaf_solve_lds = 0;
     int leaf_solve_mode = 2;              // MRA_OPT_LEAF_SOLVE: 0 off, 1 always, 2 (default) when the leaves are few per CU
     size_t n_trsm_small = 0;            // the *Plain arrays are ordered: leaves with nt <= 8 first
@@ -870,6 +873,12 @@ static void build_leaf(mra_plan* pl, const double* y) {
                 }
             pl->gLeafSolve.upload(sp);
             pl->gLeafUpdatePlain.upload(up);
+            {
+                std::vector<long> lr0(nl);
+                std::vector<unsigned char> lup(nl);
+                for (size_t t = 0; t < nl; ++t) { lr0[t] = pl->row0[pl->leaf_nodes[t]]; lup[t] = tf[t].nt <= 8 ? 1 : 0; }
+                pl->leaf_row0_dev.upload(lr0); pl->leaf_upd_dev.upload(lup);
+            }
             const int nts = pl->trsm_small_nt;
             pl->leaf_solve_lds = (size_t)((nts * (nts - 1) / 2 + nts) * FT_SZ + 2 * nat_max * 16 * LG_LD) * sizeof(double);
             pl->leaf_solve_ok = pl->n_trsm_small > 0 && nat_max <= 13 && nat_max > 0 && pl->leaf_solve_lds <= 160 * 1024 && pl->leaf_max_rows >= 128;
@@ -1109,8 +1118,13 @@ static void run_prior_fused(mra_plan* pl) {
 template <int CWT, int NLMAX, int WPW>
 static void launch_predict_cascade_w(mra_plan* pl, const PredArgs& ar, size_t lds) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+    if (!attr) {
+        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (ar.leaf_upd) hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, true>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+    else hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, false>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
 }
 template <int CWT, int NLMAX>
 static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
@@ -1129,9 +1143,16 @@ static void run_predict_fused(mra_plan* pl) {
     ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p; ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
     ar.n_wg = pl->n_fwg; ar.nl = pl->NL;
     const int cwt = pl->CWT, mmax = pl->NL - 1;
-    const size_t lds = (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax * cwt + 1) * cwt) * 2048;
+    size_t lds = (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax * cwt + 1) * cwt) * 2048;
     double fl = 0;
     for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
+    if (pl->pred_update_now) {
+        // the leaf update rides in this launch (two Ut chunk stages share the LDS with the level operands)
+        ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
+        ar.leaf_upd = pl->leaf_upd_dev.p; ar.na = pl->na[pl->NL];
+        lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 16 * LG_LD) * sizeof(double));
+        fl += pl->fl_leaf_update;
+    }
     KTimer kt(pl, KF_PRED_UPDATE, fl);
     if (ar.n_wg <= 0) return;
     if (cwt == 1) launch_predict_cascade<1, 8>(pl, ar, lds);
@@ -1372,6 +1393,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     }
     pl->side_pending = false;
     pl->split_pending = false;
+    pl->pred_update_now = false;
     pl->pass_open = true;
     pl->run_flags = flags;
     for (int k = 0; k < KF_COUNT; ++k) pl->kstat[k] = mra_plan::KStat();
@@ -1505,7 +1527,16 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                                    pl->row_leaf.p, pl->W.p, (long)pl->ldw, pl->Ka, pl->var.p, cov0,
                                    pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
             }
-            if (solve_fused) {
+            pl->pred_update_now = !solve_fused && fused && pl->use_pred_update && pl->leaf_solve_ok && pl->leaf_max_nop / 16 <= 12 &&
+                                  pl->na[pl->NL] == (pl->NL * pl->CWT + 1) * 16;
+            if (pl->pred_update_now) {
+                // the small leaves (<= 8 observation tiles) take their update inside the predictive cascade; the few larger ones here
+                const size_t ns = pl->n_trsm_small;
+                if (nl > ns) {
+                    KTimer kt(pl, KF_LEAF_UPDATE, 0);
+                    launch_gemm<EPI_SUB>(pl, pl->gLeafUpdatePlain.p + ns, nl - ns, pl->leaf_max_rows, pl->leaf_max_na);
+                }
+            } else if (solve_fused) {
                 // Tt = V Lc^-T, var -= |Tt|^2 and W -= Tt Ut^T in one launch for the leaves with <= 8 observation tiles; the few
                 // larger ones went through the full row solve above and take the plain update product
                 static bool attr = false;
@@ -1854,6 +1885,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 5) { pl->use_knot_chain = value != 0; return MRA_OK; }
     if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
     if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
+    if (option == 8) { pl->use_pred_update = value != 0; return MRA_OK; }
     if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
 }

@@ -19,9 +19,10 @@ def family(name, grid, maxgrid):
     if name.startswith("void k_prior_cascade"):
         return "k_prior_cascade row pass (W of all levels, Ut scatter)" if grid == maxgrid.get("cascade") else KNOT
     if name.startswith("void k_knot_chain"): return KNOT
-    if name.startswith("void k_predict_cascade"): return "k_predict_cascade (all levels, mean/var)"
+    if name.startswith("void k_predict_cascade"): return "k_predict_cascade (leaf update + all levels, mean/var)"
     if name.startswith("void k_leaf_gemm<2"): return "k_leaf_gemm<COV> leaf residual V[S,o] and C"
-    if name.startswith("void k_leaf_gemm<1") or name.startswith("void k_gemm_nt_lds<1"): return "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut"
+    if name.startswith("void k_leaf_gemm<1") or name.startswith("void k_gemm_nt_lds<1") or name.startswith("void k_leaf_solve_update"):
+        return "k_gemm_nt_lds<SUB> / k_leaf_solve_update leaf update (separate launch)"
     if name.startswith("void k_parent_front"): return "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)"
     if name.startswith("void k_front"): return "k_front (assembly + partial Cholesky + Schur per level)"
     if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)"
