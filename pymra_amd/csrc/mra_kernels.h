@@ -1390,7 +1390,7 @@ struct CascadeArgs {
     double* invd_out;         // [node][cwt][256]
     int* err;
     unsigned long long* stamps;   // diagnostic build (-DMRA_STAMPS) only: 16 s_memtime stamps per row tile
-    int dbg;                  // what-if timing switches (results are wrong when set): 1 no Ut scatter, 2 no W stores, 4 constant instead of kernel evaluation
+    int dbg;                  // what-if timing switches (results are wrong when set): 1 no Ut scatter, 2 no W stores, 4 constant instead of kernel evaluation, 8 (valid results) predictive cascade at two workgroups per CU
     int node_base;            // KNOT: node number of slot 0 of the level being factorised (error reports name node + 1)
 };
 
@@ -1882,6 +1882,7 @@ struct PredLevel {
 };
 struct PredArgs {
     PredLevel lev[8];
+    PredLevel deep;           // = lev[nl - 1] (a run-time index into lev[] would put the whole argument block in scratch)
     const double* W;
     double* mean;
     double* var;
@@ -1902,11 +1903,20 @@ struct PredArgs {
     const long* leaf_row0;    // [leaf] first padded row
     const unsigned char* leaf_upd;   // [leaf] 1: update here (nop <= 128); 0: a separate product has done it
     int na;                   // rows of Ut = ancestors + y block
+    unsigned long long* stamps;   // diagnostic build (-DMRA_STAMPS) only: 16 s_memtime stamps per row tile
 };
+#ifdef MRA_STAMPS
+#define MRA_PSTAMP(slot) do { if (ar.stamps && active && lane == 0) ar.stamps[(t) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MRA_PSTAMP_WALL(slot) do { if (ar.stamps && active && lane == 0) ar.stamps[(t) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MRA_PSTAMP(slot) do { } while (0)
+#define MRA_PSTAMP_WALL(slot) do { } while (0)
+#endif
 
-#define MRA_PRED_STAGE_ISSUE(ms) do { \
+#define MRA_PRED_STAGE_ISSUE(ms) MRA_PRED_STAGE_ISSUE_L(ms, ar.lev[ms])
+#define MRA_PRED_STAGE_ISSUE_L(ms, lvl) do { \
                 const int ms_ = (ms); \
-                const PredLevel ls = ar.lev[ms_]; \
+                const PredLevel ls = (lvl); \
                 const int slot_s = chain[ms_]; \
                 const double* Fs = ls.F + (long)slot_s * ls.nf * ls.nf; \
                 const double* invs = ls.invF + (long)slot_s * CWT * 256; \
@@ -1934,8 +1944,8 @@ _Pragma("unroll") \
                     } \
                 } \
 } while (0)
-template <int CWT, int NLMAX, int WPW, bool UPD>
-__global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
+template <int CWT, int NLMAX, int WPW, bool UPD, int MINB>
+__global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int CW = CWT * 16;
     constexpr int NTRI = CWT * (CWT - 1) / 2;
@@ -1947,6 +1957,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const long t0 = ar.wg_tile0[blockIdx.x];
     const int nt_wg = ar.wg_ntiles[blockIdx.x];
+    if (nt_wg == 0) return;                                 // padding slot of the XCD-dealt workgroup order
     const bool active = wave < nt_wg;
     const long t = t0 + (active ? wave : 0);
     const int prow = pi16(r);
@@ -1964,71 +1975,90 @@ __global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
     }
     d4 yt = *(const d4*)(wrow + ar.ycol);
     double ssq = 0.0;
+    MRA_PSTAMP(0);
+    MRA_PSTAMP_WALL(13);
+    bool pre_issued = false;
     if (UPD) {
         const int lf = ar.tile_leaf[t0];                    // all tiles of a workgroup belong to one leaf
-        const int nt = ar.leaf_upd[lf] ? (ar.leaf_nop[lf] >> 4) : 0;
-        if (nt > 0) {
+        const int nc = ar.leaf_upd[lf] ? (ar.leaf_nop[lf] >> 3) : 0;      // chunks of 8 k
+        if (nc > 0) {
             const long nop = ar.leaf_nop[lf];
             const double* ut = ar.leaf_ut[lf];
-            const double* tt = ut + (long)ar.na * nop + (myrow - ar.leaf_row0[lf]) * nop + 4 * q;
-            d4 x[8];                                         // -Tt fragments of the row tile (nop <= 128)
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) x[kb] = (kb < nt) ? -(*(const d4*)(tt + kb * 16)) : zero;
+            // Tt fragments of the row tile, one 16 x 8 chunk at a time (lane (r, q) holds k = 2q, 2q+1 of the chunk), fetched
+            // one chunk ahead: holding all of Tt would cost 32 registers and the third wave per SIMD with them
+            const double* tt = ut + (long)ar.na * nop + (myrow - ar.leaf_row0[lf]) * nop + 2 * q;
             yt = zero;                                       // the y block takes C_in = 0 (the column still holds y itself)
             const int nat = ar.nl * CWT + 1;
-            const int nch = nat * 64;                        // 32-byte pieces of a (nat*16) x 16 chunk of Ut
+            const int nch = nat * 64;                        // 16-byte pieces of a (nat*16) x 8 chunk of Ut, 4 per row
             constexpr int NSTU = ((NLMAX * CWT + 1) * 64 + NTH - 1) / NTH;
-            double* const sU0 = lds;
-            double* const sU1 = lds + (long)nat * 16 * LG_LD;
-            bool on[NSTU];
-            int so[NSTU];
+            double* cur = lds;
+            double* nxt = lds + (long)nat * 128;
             const double* up[NSTU];
-            d4 sg[NSTU];
+            d2 sg[NSTU];
 #pragma unroll
             for (int g = 0; g < NSTU; ++g) {
                 const int e = (int)threadIdx.x + g * NTH;
-                on[g] = e < nch;
-                so[g] = (e >> 2) * LG_LD + ((e & 3) << 2);
-                up[g] = ut + (long)(on[g] ? e >> 2 : 0) * nop + ((e & 3) << 2);
-                sg[g] = *(const d4*)(up[g]);
+                up[g] = ut + (long)(e < nch ? e >> 2 : 0) * nop + ((e & 3) << 1);
+                sg[g] = *(const d2*)(up[g]);
             }
+            d2 xc = *(const d2*)tt;
 #pragma unroll
-            for (int g = 0; g < NSTU; ++g) if (on[g]) *(d4*)(sU0 + so[g]) = sg[g];
+            for (int g = 0; g < NSTU; ++g) { const int e = (int)threadIdx.x + g * NTH; if (e < nch) *(d2*)(cur + 2 * e) = sg[g]; }
             __syncthreads();
+            MRA_PSTAMP(1);
+// one 8-k chunk: the Ut fragments of level k+1 are read while the products of level k issue, and no further ahead (left
+// alone the scheduler hoists all 13 LDS reads to the top: 52 registers, and with them the third wave per SIMD)
+#define MRA_PRED_UPD_CHUNK() do { \
+                if (active) { \
+                    const double x0 = -xc[0], x1 = -xc[1]; \
+                    const double* cb = cur + prow * 8 + 2 * q; \
+                    d2 bq[2][CWT]; \
+_Pragma("unroll") \
+                    for (int kt = 0; kt < CWT; ++kt) bq[0][kt] = *(const d2*)(cb + ((ar.nl - 1) * CWT + kt) * 128); \
+_Pragma("unroll") \
+                    for (int k = 0; k < NLMAX; ++k) { \
+                        if (k < ar.nl) { \
+                            if (k + 1 < ar.nl) { \
+_Pragma("unroll") \
+                                for (int kt = 0; kt < CWT; ++kt) bq[(k + 1) & 1][kt] = *(const d2*)(cb + ((ar.nl - 2 - k) * CWT + kt) * 128); \
+                            } else { \
+                                bq[(k + 1) & 1][0] = *(const d2*)(cb + (ar.nl * CWT) * 128); \
+                            } \
+_Pragma("unroll") \
+                            for (int kt = 0; kt < CWT; ++kt) { \
+                                w[k][kt] = mfma16(bq[k & 1][kt][0], x0, w[k][kt]); \
+                                w[k][kt] = mfma16(bq[k & 1][kt][1], x1, w[k][kt]); \
+                            } \
+                            __builtin_amdgcn_sched_barrier(0); \
+                            if (k + 1 == ar.nl) { \
+                                yt = mfma16(bq[(k + 1) & 1][0][0], x0, yt); \
+                                yt = mfma16(bq[(k + 1) & 1][0][1], x1, yt); \
+                            } \
+                        } \
+                    } \
+                } \
+} while (0)
+#pragma nounroll
+            for (int c = 0; c + 1 < nc; ++c) {
+                const int kn = (c + 1) * 8;
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                if (kb < nt) {
-                    const double* st = (kb & 1) ? sU1 : sU0;
-                    const int kn = (kb + 1 < nt ? kb + 1 : kb) * 16;
+                for (int g = 0; g < NSTU; ++g) sg[g] = *(const d2*)(up[g] + kn);
+                const d2 xn = *(const d2*)(tt + kn);
+                MRA_PRED_UPD_CHUNK();
 #pragma unroll
-                    for (int g = 0; g < NSTU; ++g) sg[g] = *(const d4*)(up[g] + kn);
-                    if (active) {
-#pragma unroll
-                        for (int k = 0; k < NLMAX; ++k) {
-                            if (k < ar.nl) {
-#pragma unroll
-                                for (int kt = 0; kt < CWT; ++kt) {
-                                    const int j = (ar.nl - 1 - k) * CWT + kt;
-                                    const d4 b = *(const d4*)(st + (j * 16 + prow) * LG_LD + 4 * q);
-#pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4) w[k][kt] = mfma16(b[s4], x[kb][s4], w[k][kt]);
-                                }
-                            }
-                        }
-                        const d4 b = *(const d4*)(st + ((ar.nl * CWT) * 16 + prow) * LG_LD + 4 * q);
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) yt = mfma16(b[s4], x[kb][s4], yt);
-                    }
-                    if (kb + 1 < nt) {
-                        double* sn = (kb & 1) ? sU0 : sU1;
-#pragma unroll
-                        for (int g = 0; g < NSTU; ++g) if (on[g]) *(d4*)(sn + so[g]) = sg[g];
-                        __syncthreads();
-                    }
-                }
+                for (int g = 0; g < NSTU; ++g) { const int e = (int)threadIdx.x + g * NTH; if (e < nch) *(d2*)(nxt + 2 * e) = sg[g]; }
+                __syncthreads();
+                xc = xn;
+                double* const sw = cur; cur = nxt; nxt = sw;
             }
+            // the deepest level's operands ride behind the last chunk (issued inside the loop, their address arithmetic
+            // is hoisted out of it and spills)
+            MRA_PRED_STAGE_ISSUE_L(ar.nl - 1, ar.deep);
+            pre_issued = true;
+            MRA_PRED_UPD_CHUNK();
         }
     }
+    MRA_PSTAMP(2);
 #pragma unroll
     for (int mm = 0; mm < NLMAX; ++mm) {
         const int m = NLMAX - 1 - mm;
@@ -2042,7 +2072,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
             // thread's loads are issued together, and the loads of level m-1 are issued BEFORE the
             // products of level m, so their L2 round trip (a load -> ds_write loop pays ~1 us per
             // chunk, which was half of this kernel's run time) hides behind the MFMA work.
-            if (m == ar.nl - 1) MRA_PRED_STAGE_ISSUE(m);               // the first (deepest) level of this tree
+            if (m == ar.nl - 1 && !pre_issued) MRA_PRED_STAGE_ISSUE(m);   // the first (deepest) level of this tree
             __syncthreads();                                  // the previous level's products are done with the LDS image
             {
                 const int total = (NTRI + CWT + nzt) * 128;
@@ -2056,6 +2086,7 @@ __global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
             }
             __syncthreads();
             if (m > 0) MRA_PRED_STAGE_ISSUE(m - 1);
+            if (m < 5) MRA_PSTAMP(3 + 2 * m);
             if (active) {
                 d4 x[CWT];
 #pragma unroll
@@ -2108,8 +2139,11 @@ __global__ __launch_bounds__(64 * WPW, 2) void k_predict_cascade(PredArgs ar) {
                     yt -= acc;
                 }
             }
+            if (m < 5) MRA_PSTAMP(4 + 2 * m);
         }
     }
+    MRA_PSTAMP(15);
+    MRA_PSTAMP_WALL(14);
     if (!active) return;
     ssq += __shfl_xor(ssq, 16, 64);
     ssq += __shfl_xor(ssq, 32, 64);

@@ -183,7 +183,7 @@ struct mra_plan {
     double R = 0.0;
     int reduce_level = -1;
     // device data
-    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps;
+    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps;
     double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
     double* host_res_dev = nullptr;  // the same memory as the device sees it
     DevVec<int> errflag, knot_idx, row_leaf;
@@ -248,9 +248,9 @@ struct mra_plan {
         int k_threads = 256;        // workgroup size of the level's knot launch (512 when sibling families share a workgroup)
     };
     std::vector<FusedLevel> fl;
-    DevVec<long> ft_row0, ft_wg0;
-    DevVec<int> ft_chain, ft_wgn;
-    long n_ftiles = 0, n_fwg = 0;
+    DevVec<long> ft_row0, ft_wg0, ft_wg0_x;
+    DevVec<int> ft_chain, ft_wgn, ft_wgn_x;
+    long n_ftiles = 0, n_fwg = 0, n_fwg_x = 0;
     size_t cascade_lds = 0, cascade_lds_all = 0;
     bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
     bool cascade_group_siblings = false;
@@ -635,6 +635,20 @@ static void build_static(mra_plan* pl) {
         pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains); pl->ft_leaf.upload(tleaf);
         pl->n_ftiles = (long)r0s.size();
         pl->ft_wg0.upload(fwg0); pl->ft_wgn.upload(fwgn); pl->n_fwg = (long)fwg0.size();
+        {
+            // the same workgroups ordered for the predictive cascade: workgroup b runs on XCD b % 8, and the workgroups of
+            // one leaf all stream that leaf's Ut block, so they are dealt to one XCD (one L2) -- empty slots pad the lanes
+            std::vector<std::vector<size_t>> lane(8);
+            for (size_t g = 0; g < fwg0.size(); ++g) lane[(size_t)tleaf[(size_t)fwg0[g]] % 8].push_back(g);
+            size_t deep = 0;
+            for (const auto& l : lane) deep = std::max(deep, l.size());
+            std::vector<long> x0(deep * 8, 0);
+            std::vector<int> xn(deep * 8, 0);
+            for (size_t k = 0; k < deep; ++k)
+                for (size_t x = 0; x < 8; ++x)
+                    if (k < lane[x].size()) { x0[k * 8 + x] = fwg0[lane[x][k]]; xn[k * 8 + x] = fwgn[lane[x][k]]; }
+            pl->ft_wg0_x.upload(x0); pl->ft_wgn_x.upload(xn); pl->n_fwg_x = (long)x0.size();
+        }
         {
             const int cwt = pl->CWT, mmax = pl->NL - 1;
             pl->cascade_lds = (size_t)(cwt * mmax * cwt + cwt * (cwt - 1) / 2 + cwt) * 2048;
@@ -1115,21 +1129,25 @@ static void run_prior_fused(mra_plan* pl) {
     }
 }
 
-template <int CWT, int NLMAX, int WPW>
+// MINB workgroups per CU: three when both the LDS image and the register budget (168 with three waves per SIMD) allow it
+template <int CWT, int NLMAX, int WPW, int MINB>
 static void launch_predict_cascade_w(mra_plan* pl, const PredArgs& ar, size_t lds) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, false, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, true, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (ar.leaf_upd) hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, true>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
-    else hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, false>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+    if (ar.leaf_upd) hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, true, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+    else hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, false, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
 }
 template <int CWT, int NLMAX>
 static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
-    if (pl->cascade_wpw == 8) launch_predict_cascade_w<CWT, NLMAX, 8>(pl, ar, lds);
-    else if (pl->cascade_wpw == 4) launch_predict_cascade_w<CWT, NLMAX, 4>(pl, ar, lds);
+    if (pl->cascade_wpw == 8) launch_predict_cascade_w<CWT, NLMAX, 8, 1>(pl, ar, lds);
+    else if (pl->cascade_wpw == 4) {
+        if (CWT <= 2 && NLMAX <= 6 && 3 * lds <= 160 * 1024 && !(pl->dbg & 8)) launch_predict_cascade_w<CWT, NLMAX, 4, (CWT <= 2 && NLMAX <= 6) ? 3 : 2>(pl, ar, lds);
+        else launch_predict_cascade_w<CWT, NLMAX, 4, 2>(pl, ar, lds);
+    }
     else throw MraError(MRA_ERR_STATE, "cascade_wpw must be 4 or 8");
 }
 
@@ -1139,9 +1157,10 @@ static void run_predict_fused(mra_plan* pl) {
         ar.lev[m].F = pl->lev[m].F.p; ar.lev[m].invF = pl->lev[m].invF.p; ar.lev[m].nf = pl->lev[m].nf;
         ar.coff[m] = pl->coff[m];
     }
+    ar.deep = ar.lev[pl->NL - 1];
     ar.W = pl->W.p; ar.mean = pl->mean.p; ar.var = pl->var.p; ar.ldw = pl->ldw; ar.ycol = pl->Ka;
-    ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p; ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p;
-    ar.n_wg = pl->n_fwg; ar.nl = pl->NL;
+    ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p; ar.wg_tile0 = pl->ft_wg0_x.p; ar.wg_ntiles = pl->ft_wgn_x.p;
+    ar.n_wg = pl->n_fwg_x; ar.nl = pl->NL;
     const int cwt = pl->CWT, mmax = pl->NL - 1;
     size_t lds = (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax * cwt + 1) * cwt) * 2048;
     double fl = 0;
@@ -1150,13 +1169,17 @@ static void run_predict_fused(mra_plan* pl) {
         // the leaf update rides in this launch (two Ut chunk stages share the LDS with the level operands)
         ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
         ar.leaf_upd = pl->leaf_upd_dev.p; ar.na = pl->na[pl->NL];
-        lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 16 * LG_LD) * sizeof(double));
+        lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 128) * sizeof(double));      // two 8-k chunks of Ut
         fl += pl->fl_leaf_update;
     }
+#ifdef MRA_STAMPS
+    if (!pl->pstamps.p) { pl->pstamps.alloc((size_t)pl->n_ftiles * 16); HIP_TRY(mraMemset(pl->pstamps.p, 0, pl->pstamps.n * sizeof(double))); }
+    ar.stamps = (unsigned long long*)pl->pstamps.p;
+#endif
     KTimer kt(pl, KF_PRED_UPDATE, fl);
     if (ar.n_wg <= 0) return;
     if (cwt == 1) launch_predict_cascade<1, 8>(pl, ar, lds);
-    else if (cwt == 2) launch_predict_cascade<2, 8>(pl, ar, lds);
+    else if (cwt == 2) { if (pl->NL <= 6) launch_predict_cascade<2, 6>(pl, ar, lds); else launch_predict_cascade<2, 8>(pl, ar, lds); }
     else launch_predict_cascade<4, 4>(pl, ar, lds);
 }
 
@@ -1829,6 +1852,7 @@ int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_
         if (what == 0) { src = pl->W.p; n = (int64_t)pl->W.n; }
         else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
         else if (what == 2) { src = pl->stamps.p; n = (int64_t)pl->stamps.n; }     // -DMRA_STAMPS builds: raw 64-bit clock stamps
+        else if (what == 3) { src = pl->pstamps.p; n = (int64_t)pl->pstamps.n; }   // same, predictive cascade
         else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
         *n_avail = n;
         if (out && cap > 0) HIP_TRY(mraMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
