@@ -1094,16 +1094,30 @@ struct Trsm2Prob {
 };
 
 
+#ifdef MRA_STAMPS
+#define MRA_TSTAMP(slot) do { if (stamps && (threadIdx.x & 63) == 0) stamps[((long)blockIdx.y * 64 + t) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MRA_TSTAMP_ARG , unsigned long long* stamps
+#else
+#define MRA_TSTAMP(slot) do { } while (0)
+#define MRA_TSTAMP_ARG
+#endif
 template <int NTMAX>
-__global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict__ probs, int tiles_per_wg) {
+__global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict__ probs, int tiles_per_wg MRA_TSTAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Trsm2Prob pb = probs[blockIdx.y];
+#ifdef MRA_STAMPS
+    const unsigned long long t_wg0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t_begin = blockIdx.x * tiles_per_wg;
     if (t_begin >= pb.ntiles) return;
     const int t_end = min(pb.ntiles, t_begin + tiles_per_wg);
     const int nt = pb.nt;
     const int ntri = nt * (nt - 1) / 2;
-    // ---- stage L (strictly-lower tiles, index jb(jb-1)/2+kb) and invd (after them) in LDS
+    // ---- stage L (strictly-lower tiles, index jb(jb-1)/2+kb) and invd (after them) in LDS.
+    // (Measured at C3: this 72 KB image lets ONE workgroup run per CU although 2 x 72 KB <= 160 KB; with the inverted
+    // blocks read from L2 instead the image is 56 KB, two workgroups do run per CU -- and the launch is slower, 0.93 ms
+    // against 0.77: the solve moves 3.4 GB in place and sits at ~75% of what HBM streams, more waves only contend.)
     stage_chunks<8>(lds, (ntri + nt) * 128, [&](int e) -> const double* {
         const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
         if (tile < ntri) {
@@ -1119,7 +1133,14 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
     const int nwave = blockDim.x >> 6;
     const int prow = pi16(r);
     const d4 zero = {0, 0, 0, 0};
+#ifdef MRA_STAMPS
+    const unsigned long long t_wg1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = t_begin + wave; t < t_end; t += nwave) {
+#ifdef MRA_STAMPS
+        if (stamps && lane == 0) { stamps[((long)blockIdx.y * 64 + t) * 8 + 0] = t_wg0; stamps[((long)blockIdx.y * 64 + t) * 8 + 1] = t_wg1; }
+#endif
+        MRA_TSTAMP(2);
         double* xp = pb.X + (long)t * 16 * pb.ldx + (long)r * pb.ldx + 4 * q;
         d4 x[NTMAX];
         double ssq = 0.0;
@@ -1139,6 +1160,9 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
                 }
             }
         }
+#ifdef MRA_STAMPS
+        if (stamps) { __builtin_amdgcn_s_waitcnt(0); MRA_TSTAMP(3); }
+#endif
 #pragma unroll
         for (int jb = 0; jb < NTMAX; ++jb) {
             if (jb < nt) {
@@ -1164,11 +1188,16 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
                 ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
             }
         }
+        MRA_TSTAMP(4);
         if (pb.var && t >= pb.var_tile0) {
             ssq += __shfl_xor(ssq, 16, 64);
             ssq += __shfl_xor(ssq, 32, 64);
             if (q == 0) { double* vp = pb.var + (long)(t - pb.var_tile0) * 16 + r; gst(vp, gld(vp) + pb.var_sign * ssq); }
         }
+        MRA_TSTAMP(5);
+#ifdef MRA_STAMPS
+        if (stamps && lane == 0) { stamps[((long)blockIdx.y * 64 + t) * 8 + 6] = t_real0; stamps[((long)blockIdx.y * 64 + t) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     }
 }
 
@@ -1448,14 +1477,19 @@ __device__ __forceinline__ void cascade_compute_level_kx(const double* __restric
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
         d4 acc = zero;
+        if (m > 0) {
+            // the Wk fragment of product i+1 is read while product i issues, and no further ahead (left alone the scheduler
+            // hoists every LDS read of the level to the top: up to 56 registers)
+            const double* ab = ldsb + (jb * (m * CWT)) * 256 + prow * 16 + 4 * q;
+            d4 an = *(const d4*)ab;
 #pragma unroll
-        for (int k = 0; k < NLMAX; ++k) {
-            if (k < m) {
+            for (int i = 0; i < NLMAX * CWT; ++i) {
+                if (i < m * CWT) {
+                    const d4 a = an;
+                    if (i + 1 < m * CWT) an = *(const d4*)(ab + (i + 1) * 256);
 #pragma unroll
-                for (int kt = 0; kt < CWT; ++kt) {
-                    const d4 a = *(const d4*)(ldsb + (jb * (m * CWT) + k * CWT + kt) * 256 + prow * 16 + 4 * q);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = mfma16(a[j], w[k][kt][j], acc);
+                    for (int j = 0; j < 4; ++j) acc = mfma16(a[j], w[i / CWT][i % CWT][j], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

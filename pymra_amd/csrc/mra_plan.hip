@@ -183,7 +183,7 @@ struct mra_plan {
     double R = 0.0;
     int reduce_level = -1;
     // device data
-    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps;
+    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps, tstamps;
     double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
     double* host_res_dev = nullptr;  // the same memory as the device sees it
     DevVec<int> errflag, knot_idx, row_leaf;
@@ -986,18 +986,32 @@ static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int
     }
     const size_t lds = (size_t)(nt * (nt - 1) / 2 + nt) * 2048;
     const unsigned gx = (unsigned)((max_tiles + tiles_per_wg - 1) / tiles_per_wg);
+    const unsigned tb = 512;
+#ifdef MRA_STAMPS
+    // the last big launch wins the buffer (tools/stamps_trsm.py reads it after a pass)
+    unsigned long long* tst = nullptr;
+    if (nprob >= 1024 && max_tiles <= 64) {
+        if (pl->tstamps.n < nprob * 64 * 8) { pl->tstamps.alloc(nprob * 64 * 8); HIP_TRY(mraMemset(pl->tstamps.p, 0, pl->tstamps.n * sizeof(double))); HIP_TRY(hipDeviceSynchronize()); }
+        tst = (unsigned long long*)pl->tstamps.p;
+    }
+#define MRA_TSTAMP_VAL , tst
+#else
+#define MRA_TSTAMP_VAL
+#endif
     for (size_t off = 0; off < nprob; off += 65535) {
         dim3 grid(gx, (unsigned)std::min<size_t>(65535, nprob - off));
-        if (nt <= 2) hipLaunchKernelGGL((k_trsm_rows2<2>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
-        else if (nt <= 4) hipLaunchKernelGGL((k_trsm_rows2<4>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
-        else if (nt <= 8) hipLaunchKernelGGL((k_trsm_rows2<8>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
-        else hipLaunchKernelGGL((k_trsm_rows2<12>), grid, dim3(512), lds, pl->stream, probs + off, tiles_per_wg);
+        if (nt <= 2) hipLaunchKernelGGL((k_trsm_rows2<2>), grid, dim3(tb), lds, pl->stream, probs + off, tiles_per_wg MRA_TSTAMP_VAL);
+        else if (nt <= 4) hipLaunchKernelGGL((k_trsm_rows2<4>), grid, dim3(tb), lds, pl->stream, probs + off, tiles_per_wg MRA_TSTAMP_VAL);
+        else if (nt <= 8) hipLaunchKernelGGL((k_trsm_rows2<8>), grid, dim3(tb), lds, pl->stream, probs + off, tiles_per_wg MRA_TSTAMP_VAL);
+        else hipLaunchKernelGGL((k_trsm_rows2<12>), grid, dim3(tb), lds, pl->stream, probs + off, tiles_per_wg MRA_TSTAMP_VAL);
     }
     return true;
 }
 
 template <int CWT, int NLMAX, int DIM, int MODE>
 static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
+    // (the row pass with twelve waves per workgroup, three per SIMD, was measured at C3: 168 registers per lane spill
+    // 264 bytes and 64 row tiles do not divide over twelve waves -- 1.44 ms against 1.29 ms with eight)
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1852,7 +1866,8 @@ int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_
         if (what == 0) { src = pl->W.p; n = (int64_t)pl->W.n; }
         else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
         else if (what == 2) { src = pl->stamps.p; n = (int64_t)pl->stamps.n; }     // -DMRA_STAMPS builds: raw 64-bit clock stamps
-        else if (what == 3) { src = pl->pstamps.p; n = (int64_t)pl->pstamps.n; }   // same, predictive cascade
+        else if (what == 3) { src = pl->pstamps.p; n = (int64_t)pl->pstamps.n; }
+        else if (what == 4) { src = pl->tstamps.p; n = (int64_t)pl->tstamps.n; }   // same, leaf row solves   // same, predictive cascade
         else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
         *n_avail = n;
         if (out && cap > 0) HIP_TRY(mraMemcpy(out, src, (size_t)std::min(cap, n) * sizeof(double), hipMemcpyDeviceToHost));
