@@ -165,7 +165,7 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_LEAF_GEMM      6   /* 1 (default): leaf-resident residual product (k_leaf_gemm, one workgroup per leaf); 2: also the leaf
                                       update; 0: 64x64-tile k_gemm_nt_lds for both */
 #define MRA_OPT_LEAF_SOLVE     7   /* row solve Tt = V Lc^-T and leaf update in one launch (k_leaf_solve_update, Tt stays in registers):
-                                      2 (default) when a CU sees at most four leaves (sharded runs), 1 always, 0 never */
+                                      2 (default) when a CU sees at most two leaves (8-way sharded runs), 1 always, 0 never */
 #define MRA_OPT_PRED_UPDATE    8   /* 1 (default): the leaf update is applied inside the predictive cascade (W is not rewritten); 0: separate product */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);

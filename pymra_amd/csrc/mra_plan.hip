@@ -1505,10 +1505,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
                 if (fused) {
                     // with the fused row solve + update the small leaves only need their Ut rows solved here
-                    // (one 8-wave workgroup per CU: a gain when a CU sees few leaves - 1.20 -> 1.14 ms on an eighth of C3, 1.97 -> 1.92
-                    // on a quarter - and neutral at sixteen per CU, where the separate kernels overlap better)
+                    // (one 8-wave workgroup per CU: a gain when a CU sees at most two leaves - 1.21 -> 1.13 ms on an eighth of C3 -
+                    // and a loss from four per CU on - 1.87 -> 1.90 ms on a quarter - where the update rides in the predictive
+                    // cascade at three workgroups per CU)
                     solve_fused = pred && pl->use_leaf_solve && pl->leaf_solve_ok &&
-                                  (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(4 * pl->n_cu));
+                                  (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(2 * pl->n_cu));
                     const Trsm2Prob* base = pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p;
                     const size_t ns = pl->n_trsm_small;
                     const int mts = (pred && !solve_fused) ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
