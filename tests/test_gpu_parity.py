@@ -363,6 +363,48 @@ def test_single_launch_chains_equal_per_level_launches(hip, name):
     pl.close()
 
 
+@pytest.mark.parametrize("n,r,M", [(768, 16, 7), (768, 32, 7), (384, 16, 6), (192, 32, 4)])
+def test_fused_cascades_at_every_depth(hip, n, r, M):
+    """The fused cascades are instantiated for up to 6 levels (three workgroups per CU in the predictive cascade) and up to
+    8; config C3 only reaches the first.  Regular trees of 7, 6 and 4 levels with one and two column tiles per level:
+    the fused launches must have run (kernel statistics) and agree with the level-by-level kernels on the same plan; the
+    6-level tree is also checked against the oracle."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    np.random.seed(5)
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y = np.random.normal(size=(n * n, 1))
+    y_obs = np.where(np.random.uniform(size=(n * n, 1)) < 0.4, y, np.nan)
+    topo = build_topology(locs, r, M, 4)
+    assert [int(v) for v in np.diff(topo.level_ptr)] == [4 ** k for k in range(M + 1)]
+    spec = mt.KernelSpec(mt.KIND_MATERN32, 0.25, 1.2)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=2e-2))
+    pl = hip.HipPlan(topo, 0); pl.set_locs(locs); pl.set_obs(y_obs, 2e-2); pl.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+    pl.set_option(1, 1)                                   # kernel timing: launches per kernel family
+    pl.run(True, True)
+    d, u = pl.likelihood(); lik = d + u
+    mean, var = pl.predict()
+    ran = {k["name"]: k["launches"] for k in pl.kernel_stats()}
+    assert any("k_predict_cascade" in nm and c > 0 for nm, c in ran.items()), ran
+    assert any("k_prior_cascade row pass" in nm and c > 0 for nm, c in ran.items()), ran
+    pl.set_option(8, 0)                                   # leaf update as a product of its own, then the cascade
+    pl.run(True, True)
+    m1, v1 = pl.predict()
+    assert abs(sum(pl.likelihood()) - lik) <= 1e-12 * abs(lik)
+    assert np.max(np.abs(m1 - mean)) < 1e-10 and K.rel(np.sqrt(v1), np.sqrt(var)) < 1e-9
+    pl.set_option(8, 1); pl.set_option(2, 0)              # MRA_OPT_FUSED off: level-by-level kernels
+    pl.run(True, True)
+    m2, v2 = pl.predict()
+    assert abs(sum(pl.likelihood()) - lik) <= 1e-11 * abs(lik)
+    assert np.max(np.abs(m2 - mean)) < 1e-9 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-8
+    if M == 6:
+        from oracle.mra_levelwise import run_levelwise
+        ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
+        assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+        assert np.max(np.abs(mean - ref["mean"])) < 1e-9 and K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+    pl.close()
+
+
 @pytest.mark.parametrize("n,r,M,fused", [(128, 64, 3, True), (128, 64, 5, False), (96, 48, 2, True), (64, 16, 3, True)])
 def test_wide_blocks_and_deep_trees(hip, n, r, M, fused):
     """r0 = 64 (4 column tiles per level: C5-like) on the fused path (CWT=4) and, when the cascades'
