@@ -555,8 +555,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
 #define LG_LD 20
 // RT row tiles per wave, CT column tiles per pass: <2, 7> for the leaf residual (N = observations, <= 7 tiles in one pass at
 // C3), <1, 13> for the leaf update (N = ancestors + y = 13 tiles: one pass, so that Tt is read from HBM once)
-template <int EPI, int DIM, int MODE, int RT, int CT>
-__global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict__ probs, KernelParams kp) {
+// NTHR threads per workgroup, WPE waves per SIMD the register budget is cut for (the second __launch_bounds__ argument is
+// waves per SIMD on HIP): <2, 7, 256, 2> holds 2 x 7 accumulators per wave at two waves per SIMD; <1, 7, 512, 4> one row
+// tile per wave at 128 registers, two 8-wave workgroups = four waves per SIMD
+template <int EPI, int DIM, int MODE, int RT, int CT, int NTHR, int WPE>
+__global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restrict__ probs, KernelParams kp) {
     __shared__ __attribute__((aligned(16))) double sB[2][CT * 16 * LG_LD];
     __shared__ double sXB[CT * 16 * DIM];
     __shared__ int sIB[CT * 16];
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
     double* const C = pp->C; const long ldc = pp->ldc;
     const int zc = pp->zc;
     const d4 zero = {0, 0, 0, 0};
-    constexpr int NST = (CT * 64 + 255) / 256;                   // 32-byte staging chunks per thread (256 threads)
+    constexpr int NST = (CT * 64 + NTHR - 1) / NTHR;             // 32-byte staging chunks per thread
     for (int rg = 0; rg < ntm; rg += RT * nwave) {
         bool vr[RT];
         long rowh[RT];
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void k_leaf_gemm(const GemmProb* __restrict
             const double* bp[NST];
 #pragma unroll
             for (int g = 0; g < NST; ++g) {
-                const int e = threadIdx.x + g * 256;
+                const int e = threadIdx.x + g * NTHR;
                 on[g] = e < nchunk;
                 const int sr = e >> 2, sc = (e & 3) << 2;
                 so[g] = sr * LG_LD + sc;

@@ -956,9 +956,15 @@ template <int EPI>
 static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) {
     if (!nprob) return;
     const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
-    const dim3 grid((unsigned)nprob), block(256);
-    constexpr int RT = (EPI == EPI_SUB) ? 1 : 2, CT = (EPI == EPI_SUB) ? 13 : 7;
-#define MRA_LG_LAUNCH(D, MD) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), RT, CT>), grid, block, 0, pl->stream, probs, pl->kp)
+    const dim3 grid((unsigned)nprob);
+    constexpr int CT = (EPI == EPI_SUB) ? 13 : 7;
+    // COV: one row tile per wave, 8 waves, 8 column tiles per pass (leaves of up to 128 observations in one pass), 128 registers =
+    // four waves per SIMD (the Kanter taper's sin/cos need 217: two); dbg bit 32: the 2-row-tile, 4-wave, 7-column, 239-register shape
+    const bool wide = (EPI == EPI_COV) && !(pl->dbg & 32);
+#define MRA_LG_LAUNCH(D, MD) do { \
+        if (wide) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), 1, 8, 512, (MD == 3 ? 2 : 4)>), grid, dim3(512), 0, pl->stream, probs, pl->kp); \
+        else hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), (EPI == EPI_SUB ? 1 : 2), CT, 256, 2>), grid, dim3(256), 0, pl->stream, probs, pl->kp); \
+    } while (0)
     if (pl->d == 1) { if (mode == 0) MRA_LG_LAUNCH(1, 0); else if (mode == 1) MRA_LG_LAUNCH(1, 1); else if (mode == 2) MRA_LG_LAUNCH(1, 2); else MRA_LG_LAUNCH(1, 3); }
     else { if (mode == 0) MRA_LG_LAUNCH(2, 0); else if (mode == 1) MRA_LG_LAUNCH(2, 1); else if (mode == 2) MRA_LG_LAUNCH(2, 2); else MRA_LG_LAUNCH(2, 3); }
 #undef MRA_LG_LAUNCH

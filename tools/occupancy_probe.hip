@@ -20,7 +20,7 @@ int main() {
     probe("k_predict_cascade<2,6,4,true,3>", k_predict_cascade<2, 6, 4, true, 3>, 256, 25 * 2048);
     probe("k_predict_cascade<2,6,4,true,2>", k_predict_cascade<2, 6, 4, true, 2>, 256, 25 * 2048);
     probe("k_prior_cascade<2,8,2,0,true>", k_prior_cascade<2, 8, 2, 0, true>, 512, 78 * 2048);
-    probe("k_leaf_gemm<COV,2,0,2,7>", k_leaf_gemm<EPI_COV, 2, 0, 2, 7>, 256, 0);
+    probe("k_leaf_gemm<COV,2,0,1,8,512,4>", k_leaf_gemm<EPI_COV, 2, 0, 1, 8, 512, 4>, 512, 0);
     probe("k_parent_front<12>", k_parent_front<12>, 512, 100 * 1024);
     probe("k_chol_wave<12>", k_chol_wave<12>, 256, 0);
     return 0;
