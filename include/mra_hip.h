@@ -169,9 +169,21 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_PRED_UPDATE    8   /* 1 (default): the leaf update is applied inside the predictive cascade (W is not rewritten); 0: separate product */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
+/* current value of an option (so that a caller can change one temporarily and put it back) */
+int mra_plan_get_option(mra_plan *plan, int option, int64_t *value);
+/* Raise the dynamic-LDS limit (160 KB) of every kernel the plan may launch on the plan's own device now rather than at
+ * first launch.  The attribute is per kernel AND per device, so it is recorded per plan: two MRATree objects on two
+ * devices of one process each take this path.  *n_kernels (may be NULL): kernels on record for this plan. */
+int mra_plan_prepare(mra_plan *plan, int64_t *n_kernels);
 int mra_kernel_family_count(void);
 int mra_get_kernel_stats(mra_plan *plan, int which, char *name, int name_cap, int *launches, double *ms,
                          double *flops);
+/* Work of the family's launches in the last mra_run: out[0] algorithmic flops (true ranks, true observation counts, one y
+ * column), out[1] flops the MFMA tiles execute on the 16-padded layout, out[2] algorithmic HBM bytes (every operand array of
+ * the launch read or written once), out[3] summed device milliseconds (as mra_get_kernel_stats). */
+int mra_get_kernel_work(mra_plan *plan, int which, double *out, int capacity);
+/* hipDeviceSynchronize on `device` (bench.py's barrier: the timed region needs no second GPU runtime in the process) */
+int mra_device_synchronize(int device);
 /* out[0..7] = P, ldw, Ka, n_leaves, bytes(W), bytes(leaf panels), bytes(leaf Gt), n_nodes */
 int mra_plan_info(mra_plan *plan, int64_t *out, int capacity);
 

@@ -53,7 +53,7 @@ def _cov_callable(cov):
 
 
 def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep: bool = False,
-                  reduce_level: int = -1, allreduce=None):
+                  reduce_level: int = -1, allreduce=None, lean: bool = False):
     """Returns dict(lik, d, u, mean[N], var[N], sd[N]) (+ intermediate buffers if keep)."""
     coords = np.asarray(locs, dtype=np.float64)
     if coords.ndim == 1:
@@ -100,9 +100,7 @@ def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep:
             W[r0:r1, c0 + rj:c0 + cwm] = 0.0
 
     # ---------------- leaves (observation space) ------------------------------------------------
-    for i in range(nn):
-        if not topo.node_leaf[i]:
-            continue
+    def leaf_node(i):
         m = int(topo.node_level[i])
         a0 = int(lay.asuf[m])
         na = int(lay.na[m])
@@ -141,9 +139,39 @@ def run_levelwise(topo, locs, cov, obs, R: float, *, predict: bool = True, keep:
             W[r0:r1, Ka] = 0.0
         Gt[i] = G
 
+    if not lean:
+        for i in range(nn):
+            if topo.node_leaf[i]:
+                leaf_node(i)
+
     # ---------------- non-leaf fronts, bottom-up ----------------------------------------------------
     d_below = None
-    for m in range(topo.n_levels - 1, -1, -1):
+    if lean:
+        # same arithmetic in depth-first post-order: a node's Schur block dies as soon as its parent has summed it, so only
+        # O(depth * J) blocks are alive at any time (level by level, config 5 would hold 65536 leaf blocks of 528^2)
+        if reduce_level >= 0:
+            raise ValueError("lean=True is for unsharded runs")
+
+        def post(i):
+            if topo.node_leaf[i]:
+                leaf_node(i)
+                g = Gt[i]
+                Gt[i] = None
+                return g
+            m = int(topo.node_level[i])
+            cwm, nf = int(lay.cw[m]), int(lay.nf[m])
+            F = np.zeros((nf, nf))
+            for c in topo.child_list[topo.child_ptr[i]:topo.child_ptr[i + 1]]:
+                F += post(int(c))
+            F[:cwm, :cwm] += np.eye(cwm)
+            L = np.linalg.cholesky(F[:cwm, :cwm])
+            Z = solve_triangular(L, F[:cwm, cwm:], lower=True).T
+            dnode[i] = 2.0 * np.log(np.diag(L)).sum()
+            Lt[i], Zt[i] = L, Z
+            return F[cwm:, cwm:] - Z @ Z.T
+
+        Gt[0] = post(0)
+    for m in range(topo.n_levels - 1, -1, -1) if not lean else []:
         cwm = int(lay.cw[m])
         ids = [i for i in range(int(topo.level_ptr[m]), int(topo.level_ptr[m + 1])) if not topo.node_leaf[i]]
         nf = int(lay.nf[m])

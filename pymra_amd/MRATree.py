@@ -133,6 +133,7 @@ class MRATree(object):
         else:
             mean, var = None, None
         self.root = RootView(d, u, mean, var, N, self.topology, np.asarray(locs, dtype=np.float64), spec)
+        self._node_blocks = {}
 
     def getLikelihood(self):
         return self.root.d + self.root.u
@@ -150,7 +151,10 @@ class MRATree(object):
         in level order - the attributes the reference keeps on its ``Node`` objects (pyMRA/MRANode.py:384-391,
         415-445, 486-507).  Costs two device passes."""
         from .diagnostics import collect_node_blocks
-        return collect_node_blocks(self, posterior=posterior)
+        key = bool(posterior)
+        if key not in self._node_blocks:                    # two device passes + one block download per node: kept until reevaluate()
+            self._node_blocks[key] = collect_node_blocks(self, posterior=posterior)
+        return self._node_blocks[key]
 
     def getNodesBFS(self, groupByResolution=False):
         """Nodes in breadth-first order (pyMRA/MRATree.py:101-120) as ``NodeBlocks`` records.  (In the reference
@@ -172,6 +176,7 @@ class MRATree(object):
         if spec is None:
             raise NotImplementedError("cov must be a device kernel")
         self.kernel = spec
+        self._node_blocks = {}
         self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale, spec.circular)
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()

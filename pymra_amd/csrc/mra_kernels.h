@@ -43,6 +43,12 @@ __device__ __forceinline__ void gst4(double* p, d4 v) { *(d4 MRA_AS1*)p = v; }
 
 
 #define MRA_YB 16
+// what-if timing switches that change results exist only in the diagnostic build (-DMRA_WHATIF); the product compiles them out
+#ifdef MRA_WHATIF
+#define MRA_WHATIF_BIT(dbg, bit) ((dbg) & (bit))
+#else
+#define MRA_WHATIF_BIT(dbg, bit) false
+#endif
 #define FT_LD 18                /* row stride (doubles) of a 16x16 tile held in LDS by the front / knot-chain kernels */
 #define FT_SZ (16 * FT_LD)
 
@@ -156,10 +162,12 @@ __device__ __forceinline__ double pair_dist2(const double* __restrict__ xa, cons
 }
 
 // diagnostics / tests: kernel values for an array of distances
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_eval_kernel(const double* __restrict__ D, double* __restrict__ out, long n, KernelParams kp) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = cov_of_dist(kp, D[i]);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 //  batched C = f(A B^T)
@@ -485,60 +493,67 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     const bool mv1 = !narrow && (m0 + 16) < pb.M, nv1 = (n0 + 16) < pb.N;
     int bc0 = n0 + r, bc1 = n0 + 16 + r;
     if (pb.idxB) { bc0 = gldi(pb.idxB + n0 + r); bc1 = nv1 ? gldi(pb.idxB + n0 + 16 + r) : -1; }
-    // COV / HOSTCOV: everything the epilogue reads per row and per column (gather indices, coordinates,
-    // the leaf's observed-row map) is fetched here in two rounds of independent loads; read inside the
-    // element loop each load sits behind the stores of the previous element and pays its own round trip
-    long xrow8[8];
-    int op8[8];
-    double xa8[8][DIM], xb2[2][DIM];
-    if (EPI == EPI_COV || EPI == EPI_HOSTCOV) {
+    // COV / HOSTCOV: everything the epilogue reads per row and per column (gather indices, coordinates, the leaf's observed-row
+    // map) is fetched in rounds of independent loads, one 16-row half of the wave's tile at a time (both halves at once kept 64
+    // registers alive beside the accumulators and spilled 6 of them at the 128-register budget)
+    int xrow4[4];
+    int op4[4];
+    double xa4[4][DIM], xb2[2][DIM];
+    if (EPI == EPI_COV) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = min(m0 + (e >> 2) * 16 + q + 4 * (e & 3), pb.M - 1);
-            xrow8[e] = pb.idxA ? (long)gldi(pb.idxA + row) : (long)row;
-            op8[e] = pb.rowmap ? gldi(pb.rowmap + row) : -1;
-        }
-        if (EPI == EPI_COV) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) xa8[e][c] = gld(pb.XA + (xrow8[e] < 0 ? 0 : xrow8[e]) * DIM + c);
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) {
-                xb2[0][c] = gld(pb.XB + (long)(bc0 < 0 ? 0 : bc0) * DIM + c);
-                xb2[1][c] = gld(pb.XB + (long)(bc1 < 0 ? 0 : bc1) * DIM + c);
-            }
+        for (int c = 0; c < DIM; ++c) {
+            xb2[0][c] = gld(pb.XB + (long)(bc0 < 0 ? 0 : bc0) * DIM + c);
+            xb2[1][c] = gld(pb.XB + (long)(bc1 < 0 ? 0 : bc1) * DIM + c);
         }
     }
+    auto fetch_rows = [&](int mb) {
+        if (EPI == EPI_COV || EPI == EPI_HOSTCOV) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = min(mb + q + 4 * e, pb.M - 1);
+                xrow4[e] = pb.idxA ? gldi(pb.idxA + row) : row;
+                op4[e] = pb.rowmap ? gldi(pb.rowmap + row) : -1;
+            }
+            if (EPI == EPI_COV) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) xa4[e][c] = gld(pb.XA + (long)(xrow4[e] < 0 ? 0 : xrow4[e]) * DIM + c);
+            }
+        }
+    };
     auto emit = [&](d4 acc, int mb, int nb, int bcol, int ti) {
         const int col = nb + r;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int row = mb + q + 4 * s;
-            const int e8 = (ti >> 1) * 4 + s;
             double* cp = pb.C + (long)row * pb.ldc + col;
             double v;
             if (EPI == EPI_SET) v = acc[s] + ((row == col && row < pb.diag_one) ? 1.0 : 0.0);
             else if (EPI == EPI_SUB) v = -acc[s];
             else if (EPI == EPI_COV) {
-                const long xrow = xrow8[e8];
-                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa8[e8], xb2[ti & 1], kp.circular)) - acc[s];
+                const int xrow = xrow4[s];
+                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa4[s], xb2[ti & 1], kp.circular)) - acc[s];
                 v = (bcol < 0 || xrow < 0) ? 0.0 : cv;
                 if (pb.sym_diag && row == col) v = (bcol < 0) ? 1.0 : v + pb.diag_add;
-                const int op = op8[e8];
+                const int op = op4[s];
                 if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
             } else {
                 v = (bcol < 0) ? 0.0 : gld(pb.Csrc + (long)row * pb.ldcs + col) - acc[s];
-                const int op = op8[e8];
+                const int op = op4[s];
                 if (op >= 0) gst(pb.C2 + (long)op * pb.ldc + col, v + (op == col ? pb.diag_add : 0.0));
             }
             gst(cp, v);
         }
     };
+    fetch_rows(m0);
     emit(c00, m0, n0, bc0, 0);
     if (nv1) emit(c01, m0, n0 + 16, bc1, 1);
-    if (mv1) emit(c10, m0 + 16, n0, bc0, 2);
-    if (mv1 && nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
+    if (mv1) {
+        fetch_rows(m0 + 16);
+        emit(c10, m0 + 16, n0, bc0, 2);
+        if (nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -581,12 +596,14 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
         bool vr[RT];
         long rowh[RT];
         const double* ap[RT];
+        int qa = q;
+        asm volatile("" : "+v"(qa));         // opaque: the lane part of the A address is rebuilt per row group instead of being hoisted and spilled
 #pragma unroll
         for (int h = 0; h < RT; ++h) {
             const int ih = rg + wave + h * nwave;
             vr[h] = ih < ntm;
             rowh[h] = (long)(vr[h] ? ih : 0) * 16 + r;
-            ap[h] = A + rowh[h] * lda + 4 * q;
+            ap[h] = A + rowh[h] * lda + 4 * qa;
         }
         for (int j0 = 0; j0 < ntn; j0 += CT) {
             const int nc = min(CT, ntn - j0);                    // column tiles of this pass
@@ -671,6 +688,8 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
                 }
             }
             // ---- epilogue: lane (r,q) of tile (i,j) holds C[i*16 + r][j*16 + 4q .. 4q+3]
+            int qe = q;
+            asm volatile("" : "+v"(qe));     // opaque, as qa above: keeps the epilogue's lane offsets out of the K loop's register budget
 #pragma unroll
             for (int h = 0; h < RT; ++h) {
                 if (!vr[h]) continue;
@@ -686,7 +705,7 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
                 for (int j = 0; j < CT; ++j) {
                     if (j < nc) {
                         const d4 ac = acc[h][j];
-                        const int col = (j0 + j) * 16 + 4 * q;
+                        const int col = (j0 + j) * 16 + 4 * qe;
                         double* cp = C + row * ldc + col;
                         d4 v;
                         if (EPI == EPI_SET) v = ac;
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
                         else {
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
-                                const int lc = j * 16 + 4 * q + s4;
+                                const int lc = j * 16 + 4 * qe + s4;
                                 const int ib = sIB[lc];
                                 double cv;
                                 if (EPI == EPI_COV) cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, &sXB[lc * DIM], kp.circular));
@@ -834,6 +853,7 @@ struct PanelProb {
     int node;           // where to put 2*sum(log diag L)
 };
 
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restrict__ probs,
                                                      double* __restrict__ dnode, int* __restrict__ err, int accumulate = 0) {
     const PanelProb pb = probs[blockIdx.x];
@@ -907,6 +927,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restri
     // accumulate: a later 64-column step of a blocked factorisation (large leaves) adds its share of the log-determinant
     if (threadIdx.x == 0) dnode[pb.node] = (accumulate ? dnode[pb.node] : 0.0) + 2.0 * logacc;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 //  Cholesky of many small matrices (the leaves' C blocks): ONE WAVE per matrix, no workgroup barriers,
@@ -1008,6 +1029,7 @@ struct TrsmNode {
     int cwt;
 };
 
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ __launch_bounds__(256, 2) void k_trsm_rows(const TrsmNode* __restrict__ nodes,
                                                     const int* __restrict__ tile_node,
                                                     const long* __restrict__ tile_row0, long ntiles,
@@ -1043,6 +1065,7 @@ __global__ __launch_bounds__(256, 2) void k_trsm_rows(const TrsmNode* __restrict
         if (q == 0) var[tile_row0[t] + r] += ssq;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 //  X = R L^{-T} on 16-row tiles, second generation: L and the inverted diagonal blocks are staged in
@@ -1300,7 +1323,7 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
         // first Ut chunk in flight beside the solve
         d4 sg[NST];
 #pragma unroll
-        for (int g = 0; g < NST; ++g) sg[g] = gld4(up[g]);
+        for (int g = 0; g < NST; ++g) sg[g] = nt > 0 ? gld4(up[g]) : zero;    // a leaf without observations has a zero-sized panel
         double ssq = 0.0;
 #pragma unroll
         for (int jb = 0; jb < NTMAX; ++jb) {
@@ -1503,7 +1526,7 @@ __device__ __forceinline__ void cascade_compute_level_kx(const double* __restric
 #pragma unroll
             for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) res[j] = ((dbg & 4) ? kc[j * DIM] * 1e-3 : cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular))) - acc[j];
+            for (int j = 0; j < 4; ++j) res[j] = (MRA_WHATIF_BIT(dbg, 4) ? kc[j * DIM] * 1e-3 : cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular))) - acc[j];
         }
         d4 upd = zero;
 #pragma unroll
@@ -1555,7 +1578,9 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
     if (ar.ycol >= 0) {                 // the 16-wide y block of W: y (0 where missing) in its first column
         const double yy = ar.y[myrow];
         const d4 yt = {(q == 0 && isfinite(yy)) ? yy : 0.0, 0.0, 0.0, 0.0};
-        *(d4*)(ar.W + myrow * ar.ldw + ar.ycol + 4 * q) = yt;
+        int qo = q;
+        asm volatile("" : "+v"(qo));     // opaque: the lane part of the address is rebuilt here, not hoisted out of the tile loop and spilled
+        *(d4*)(ar.W + myrow * ar.ldw + ar.ycol + 4 * qo) = yt;
     }
     if (ar.obs_pos) {
         const int op = ar.obs_pos[myrow];
@@ -1577,10 +1602,10 @@ __device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, in
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
         const d4 v = w[m][jb];
-        if (!(ar.dbg & 2)) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+        if (!MRA_WHATIF_BIT(ar.dbg, 2)) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
         ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
-    if (op >= 0 && !(ar.dbg & 1)) {
+    if (op >= 0 && !MRA_WHATIF_BIT(ar.dbg, 1)) {
         const int lf = ar.tile_leaf[t];
         double* ut = ar.leaf_ut[lf];
         const long nop = ar.leaf_nop[lf];
@@ -2195,6 +2220,7 @@ _Pragma("unroll") \
 //  small kernels
 // ------------------------------------------------------------------------------------------------
 // W[:, Ka] = y (0 where missing), W[:, Ka+1 .. Ka+15] = 0
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_init_yblock(double* __restrict__ W, long ldw, int Ka, const double* __restrict__ y, long P) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * MRA_YB) return;
@@ -2203,9 +2229,11 @@ __global__ void k_init_yblock(double* __restrict__ W, long ldw, int Ka, const do
     if (c == 0) { double yy = y[p]; v = isfinite(yy) ? yy : 0.0; }
     W[p * ldw + Ka + c] = v;
 }
+#endif
 
 // prior: kInv block of a node = rows of its knots out of its own conditional-covariance block
 struct KinvProb { double* Lp; const long* knots; int rank; int cw; };
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_gather_kinv(const KinvProb* __restrict__ probs, const double* __restrict__ W, long ldw, int c0) {
     const KinvProb pb = probs[blockIdx.y];
     int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2215,6 +2243,7 @@ __global__ void k_gather_kinv(const KinvProb* __restrict__ probs, const double* 
     if (a < pb.rank && b < pb.rank) v = W[pb.knots[a] * ldw + c0 + b];
     pb.Lp[(long)a * pb.cw + b] = v;
 }
+#endif
 
 // leaf panel: [ C = V[o,o] + R I ; Ut = [W_anc[o] | y_o]^T ; V[S,o] ] -> fill the first two parts
 struct LeafProb {
@@ -2228,6 +2257,7 @@ struct LeafProb {
     int a0;               // first ancestor column in W
     int node;
 };
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_leaf_fill(const LeafProb* __restrict__ probs, const double* __restrict__ W, long ldw, double R) {
     const LeafProb pb = probs[blockIdx.y];
     const long total = (long)(pb.nop + pb.na) * pb.nop;
@@ -2247,8 +2277,10 @@ __global__ void k_leaf_fill(const LeafProb* __restrict__ probs, const double* __
         pb.Pn[(long)row * pb.ld + k] = v;
     }
 }
+#endif
 
 // phantom observation rows of a leaf's C block: identity (the real rows come from the COV epilogue)
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_leaf_cphantom(const LeafProb* __restrict__ probs, const int* __restrict__ n_obs) {
     const LeafProb pb = probs[blockIdx.x];
     const int no = n_obs[blockIdx.x];
@@ -2258,9 +2290,11 @@ __global__ void k_leaf_cphantom(const LeafProb* __restrict__ probs, const int* _
         pb.Pn[(long)row * pb.ld + col] = (row == col) ? 1.0 : 0.0;
     }
 }
+#endif
 
 // leaf moments: var = max(C(x,x) - |W_anc[x]|^2 - |Tt[x]|^2, 0); y column of W reset to 0.
 // One wave per row.
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ __launch_bounds__(256) void k_leaf_moments(const LeafProb* __restrict__ probs, const int* __restrict__ row_leaf,
                                                        double* __restrict__ W, long ldw, int Ka,
                                                        double* __restrict__ var, double cov0,
@@ -2285,10 +2319,12 @@ __global__ __launch_bounds__(256) void k_leaf_moments(const LeafProb* __restrict
         W[p * ldw + Ka] = 0.0;
     }
 }
+#endif
 
 // non-leaf front: F = [I on the own block] + sum of the children's Schur blocks (lower triangle)
 struct AsmProb { double* F; int nf; int cw; int child0; int nchild; int add_identity; };
 struct AsmChild { const double* G; long ld; };
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_assemble(const AsmProb* __restrict__ probs, const AsmChild* __restrict__ kids, int add_identity) {
     const AsmProb pb = probs[blockIdx.y];
     const long total = (long)pb.nf * pb.nf;
@@ -2303,11 +2339,14 @@ __global__ void k_assemble(const AsmProb* __restrict__ probs, const AsmChild* __
         pb.F[(long)a * pb.nf + b] = v;
     }
 }
+#endif
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_add_identity(const AsmProb* __restrict__ probs) {
     const AsmProb pb = probs[blockIdx.y];
     int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < pb.cw) pb.F[(long)a * pb.nf + a] += 1.0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 //  Fused non-leaf front: assembly + partial Cholesky + Schur complement in ONE launch per level, the front held
@@ -2661,11 +2700,20 @@ __global__ __launch_bounds__(512, 1) void k_parent_front(const FrontProb* __rest
         }
         __syncthreads();
     }
-    // ---- Schur update of the trailing tiles in registers, everything out
+    // ---- Schur update of the trailing tiles in registers, everything out.  The tile coordinates are worked out again from an
+    // opaque copy of the wave number (scalar arithmetic): kept from the top of the kernel they sit in registers through the K loop
+    // and the factorisation, and were spilled (19 registers, 80 B/lane)
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
 #pragma unroll
     for (int n = 0; n < NACC; ++n) {
         if (wave + 8 * n < ntiles) {
-            const int i = ti[n], j = tj[n];
+            int i = 0;
+            {
+                const int t = wv + 8 * n;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+            }
+            const int j = wv + 8 * n - i * (i + 1) / 2;
             double* gp = F + (long)(i * 16 + r) * nf + j * 16 + 4 * q;
             if (j < cwt) {
                 gst4(gp, *(const d4*)(pan + (long)tix(i, j) * FT_SZ + r * FT_LD + 4 * q));
@@ -2685,14 +2733,17 @@ __global__ __launch_bounds__(512, 1) void k_parent_front(const FrontProb* __rest
 }
 
 // mean = -W[:, Ka]
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ void k_extract_mean(const double* __restrict__ W, long ldw, int Ka, double* __restrict__ mean, long P) {
     long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < P) mean[p] = -W[p * ldw + Ka];
 }
+#endif
 
 // d = sum of per-node log-determinants, in node order (deterministic), one workgroup.  With `up` set
 // this is the last launch of a pass and out[0..3] = {d, u, log-det sum carried by the reduce level,
 // error flag} is the one record the host reads back
+#ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
 __global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dnode, int n, double* __restrict__ out,
                                                    const double* __restrict__ up = nullptr, const double* __restrict__ below = nullptr,
                                                    const int* err = nullptr) {
@@ -2715,3 +2766,4 @@ __global__ __launch_bounds__(256) void k_sum_dnode(const double* __restrict__ dn
         }
     }
 }
+#endif

@@ -1,0 +1,30 @@
+// mra_launch_pred.hip - dispatch of the predictive cascade (k_predict_cascade) over block width, depth, workgroup shape and the
+// folded leaf update; a translation unit of its own so that libmra_hip.so builds in parallel.
+#define MRA_KERNELS_TEMPLATES_ONLY
+#include "mra_plan_types.h"
+
+// MINB workgroups per CU: three when both the LDS image and the register budget (168 with three waves per SIMD) allow it
+template <int CWT, int NLMAX, int WPW, int MINB>
+static void launch_predict_cascade_w(mra_plan* pl, const PredArgs& ar, size_t lds) {
+    ensure_big_lds(pl, {(const void*)k_predict_cascade<CWT, NLMAX, WPW, false, MINB>, (const void*)k_predict_cascade<CWT, NLMAX, WPW, true, MINB>});
+    if (pl->prepare_only) return;
+    if (ar.leaf_upd) hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, true, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+    else hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, false, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
+}
+template <int CWT, int NLMAX>
+static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
+    if (pl->cascade_wpw == 8) launch_predict_cascade_w<CWT, NLMAX, 8, 1>(pl, ar, lds);
+    else if (pl->cascade_wpw == 4) {
+        if (CWT <= 2 && NLMAX <= 6 && 3 * lds <= 160 * 1024 && !(pl->dbg & 8)) launch_predict_cascade_w<CWT, NLMAX, 4, (CWT <= 2 && NLMAX <= 6) ? 3 : 2>(pl, ar, lds);
+        else launch_predict_cascade_w<CWT, NLMAX, 4, 2>(pl, ar, lds);
+    }
+    else throw MraError(MRA_ERR_STATE, "cascade_wpw must be 4 or 8");
+}
+
+void launch_predict_any(mra_plan* pl, const PredArgs& ar, size_t lds) {
+    const int cwt = pl->CWT;
+    if (cwt == 1) launch_predict_cascade<1, 8>(pl, ar, lds);
+    else if (cwt == 2) { if (pl->NL <= 6) launch_predict_cascade<2, 6>(pl, ar, lds); else launch_predict_cascade<2, 8>(pl, ar, lds); }
+    else launch_predict_cascade<4, 4>(pl, ar, lds);
+}
+

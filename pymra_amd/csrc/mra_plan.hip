@@ -8,19 +8,7 @@
 //   3. non-leaf fronts, bottom-up   (:432-480)
 //   4. predictive moments, bottom-up(:486-520)
 // DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
-#include "mra_kernels.h"
-#include "mra_topology.h"
-#include "../../include/mra_hip.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <dlfcn.h>
-#include <rccl/rccl.h>      // types and enum values only: the library itself is loaded with dlopen at run time
-#include <string>
-#include <vector>
+#include "mra_plan_types.h"
 
 static void derive_kernel_params(KernelParams& kp) {
     kp.mode = 0; kp.a1 = 0.0; kp.a2 = 0.0; kp.amp = kp.scale * kp.sig;
@@ -36,253 +24,6 @@ static void derive_kernel_params(KernelParams& kp) {
     }
     kp.c_inv_l = c / kp.l;
 }
-
-#define MRA_VERSION_STR "mra_hip 0.2 (gfx950)"
-
-// ---- host dry run (test instrumentation, never a compute path) ------------------------------------------------------
-// With MRA_HOST_DRYRUN=1 in the environment the plan is built entirely in host memory: every "device" buffer is a
-// malloc, uploads are memcpy, no stream / event / kernel is ever created and mra_run refuses to run.  The point is
-// to push the ~1500 lines of index arithmetic of plan construction (build_static, build_leaf, the host-cov block
-// bookkeeping) and the native tree replay through AddressSanitizer / UBSan on a machine without a GPU
-// (`make asan`, tests/test_asan_host.py).  Nothing is computed in this mode.
-static const bool g_dry = []() { const char* e = getenv("MRA_HOST_DRYRUN"); return e && e[0] == '1'; }();
-static inline hipError_t mraMalloc(void** p, size_t n) { if (g_dry) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; } return hipMalloc(p, n); }
-static inline hipError_t mraFree(void* p) { if (g_dry) { free(p); return hipSuccess; } return hipFree(p); }
-static inline hipError_t mraMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind k) { if (g_dry) { memcpy(d, s_, n); return hipSuccess; } return hipMemcpy(d, s_, n, k); }
-static inline hipError_t mraMemset(void* d, int v, size_t n) { if (g_dry) { memset(d, v, n); return hipSuccess; } return hipMemset(d, v, n); }
-static inline hipError_t mraMemcpy2D(void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) {
-    if (g_dry) { for (size_t i = 0; i < h; ++i) memcpy((char*)d + i * dp, (const char*)s_ + i * sp, w); return hipSuccess; }
-    return hipMemcpy2D(d, dp, s_, sp, w, h, k);
-}
-static inline hipError_t mraSetDevice(int dev) { return g_dry ? hipSuccess : hipSetDevice(dev); }
-
-static thread_local std::string g_last_error;
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t _e = (expr);                                                           \
-        if (_e != hipSuccess) {                                                           \
-            char _b[512];                                                                 \
-            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                     __FILE__, __LINE__);                                                 \
-            throw MraError(MRA_ERR_HIP, _b);                                              \
-        }                                                                                 \
-    } while (0)
-
-struct MraError {
-    int code;
-    std::string msg;
-    MraError(int c, const std::string& m) : code(c), msg(m) {}
-};
-
-enum KFam {
-    KF_PRIOR_RESID = 0, KF_PRIOR_CHOL, KF_PRIOR_TRSM, KF_LEAF_RESID, KF_LEAF_CHOL, KF_LEAF_SYRK,
-    KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
-};
-// family names = the kernels that actually run (rocprofv3 kernel names), by path: [0] fused cascades on regular trees,
-// [1] general level-by-level path.  tools/summarize_profiles.py maps the trace's kernel names onto the same strings.
-static const char* kfam_name[2][KF_COUNT] = {
-    {"k_gemm_nt_lds<COV> prior residual (unused on the fused path)",
-     "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)",
-     "k_prior_cascade row pass (W of all levels, Ut scatter)",
-     "k_leaf_gemm<COV> leaf residual V[S,o] and C",
-     "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
-     "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)",
-     "k_gemm_nt_lds<SUB> / k_leaf_solve_update leaf update (separate launch)",
-     "k_front (assembly + partial Cholesky + Schur per level)",
-     "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)",
-     "k_trsm_rows2 predict (unused on the fused path)",
-     "k_predict_cascade (leaf update + all levels, mean/var)",
-     "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"},
-    {"k_gemm_nt_lds<COV> prior residual per level",
-     "k_panel_chol prior kInv Cholesky per level",
-     "k_trsm_rows2 prior W = R L^-T per level",
-     "k_leaf_gemm<COV> leaf residual V[S,o] and C",
-     "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
-     "k_gemm_nt<SET> / k_parent_front leaf or parent SYRK",
-     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
-     "k_front / k_panel_chol front partial Cholesky",
-     "k_gemm_nt<SUB> front Schur complement",
-     "k_trsm_rows2 predict X = W Lt^-T per level",
-     "k_gemm_nt_lds<SUB> predict update per level",
-     "small kernels (k_assemble, k_gather_kinv, k_leaf_moments, k_sum_dnode, ...)"}};
-
-template <class T>
-struct DevVec {
-    T* p = nullptr;
-    size_t n = 0;
-    void upload(const std::vector<T>& h) {
-        release();
-        n = h.size();
-        if (n) {
-            if (mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
-            if (mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
-        }
-    }
-    void alloc(size_t count) {
-        release();
-        n = count;
-        if (n && mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
-            char b[160];
-            snprintf(b, sizeof b, "hipMalloc of %.3f GB failed", (double)(n * sizeof(T)) / 1e9);
-            p = nullptr;
-            throw MraError(MRA_ERR_HIP, b);
-        }
-    }
-    void release() {
-        if (p) mraFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    ~DevVec() { release(); }
-};
-
-struct LevelData {
-    std::vector<int> nodes;          // non-leaf nodes of this level
-    int cw = 0, cwt = 0, c0 = 0, a0 = 0, nf = 0, na = 0;
-    long max_rows = 0;               // largest row range among the nodes
-    DevVec<double> Lp, invP, F, invF;
-    DevVec<GemmProb> gResid, gSchur, gUpdate;
-    std::vector<GemmProb> hResid;
-    DevVec<KinvProb> gKinv;
-    DevVec<PanelProb> gPriorChol, gFrontChol;
-    DevVec<TrsmNode> gTrsmPrior, gTrsmPost;
-    DevVec<Trsm2Prob> gTrsm2Prior, gTrsm2Post;
-    long max_tiles = 0;
-    DevVec<int> tile_node;
-    DevVec<long> tile_row0;
-    long ntiles = 0;
-    DevVec<AsmProb> gAsm;
-    DevVec<FrontProb> gFront;
-    int front_mode = 0;               // 0: separate launches, 1: k_front<PANEL>, 2: k_front<FULL> (whole front in LDS)
-    size_t front_lds = 0;
-    double fl_resid = 0, fl_pchol = 0, fl_trsm = 0, fl_fchol = 0, fl_schur = 0, fl_update = 0;
-};
-
-struct mra_plan {
-    int device = 0;
-    hipStream_t stream = nullptr;        // the pass; carries the chain of small dependent launches and the all-reduce (high priority)
-    hipStream_t stream2 = nullptr;       // side stream: the leaf update runs here, beside the front chain / all-reduce (low priority)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_pending = false;           // work on stream2 that the predictive pass has to wait for
-    std::string err;
-    // topology (host)
-    long P = 0;
-    int d = 0, n_levels = 0, n_nodes = 0;
-    std::vector<long> level_ptr, row0, row1, knot_ptr, knot_rows;
-    std::vector<uint8_t> leaf;
-    std::vector<int> parent, child_ptr, child_list, cw, node_level;
-    // layout
-    int Ka = 0, ldw = 0;
-    std::vector<int> coff, asuf, nf, na;
-    // state
-    bool have_locs = false, have_obs = false, have_kernel = false, ran = false, split_pending = false;
-    uint32_t run_flags = 0;
-    KernelParams kp{};
-    bool host_cov = false;
-    double R = 0.0;
-    int reduce_level = -1;
-    // device data
-    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps, tstamps;
-    double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
-    double* host_res_dev = nullptr;  // the same memory as the device sees it
-    DevVec<int> errflag, knot_idx, row_leaf;
-    DevVec<long> knots_dev;
-    std::vector<long> knot_idx_off;      // per node offset into knot_idx (padded to cw)
-    std::vector<LevelData> lev;
-    std::vector<int> node_slot;          // index of a non-leaf node inside its level's arrays
-    // leaves
-    std::vector<int> leaf_nodes;         // node numbers
-    std::vector<int> leaf_slot;          // node -> leaf index or -1
-    std::vector<int> leaf_nop;
-    std::vector<long> leaf_poff, leaf_goff, leaf_ioff;
-    DevVec<double> panel, leafInv, Gt;
-    DevVec<int> obs_idx, obs_pos, leaf_nobs, leaf_nop_dev, ft_leaf;
-    DevVec<double*> leaf_ut;
-    DevVec<LeafProb> gLeaf;
-    DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate, gLeafResidLik;
-    std::vector<GemmProb> hLeafResid;
-    std::vector<int> leaf_nobs_host;
-    DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
-    // leaves with more than 192 observations: right-looking blocked factorisation, 64 columns per step (one panel launch +
-    // one trailing-update GEMM per step); [variant 0 full / 1 likelihood-only][step] -> descriptors of all leaves
-    std::vector<DevVec<PanelProb>> gBigPanel[2];
-    std::vector<DevVec<GemmProb>> gBigTrail[2];
-    std::vector<long> bigM[2], bigN[2];
-    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
-    DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
-    DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
-    bool use_leaf_solve = true, leaf_solve_ok = false;
-    bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
-    DevVec<long> leaf_row0_dev;
-    DevVec<unsigned char> leaf_upd_dev;
-    size_t leaf_solve_lds = 0;
-    int leaf_solve_mode = 2;              // MRA_OPT_LEAF_SOLVE: 0 off, 1 always, 2 (default) when the leaves are few per CU
-    size_t n_trsm_small = 0;            // the *Plain arrays are ordered: leaves with nt <= 8 first
-    int trsm_small_nt = 0, trsm_small_tiles_full = 0, trsm_small_tiles_lik = 0;
-    DevVec<GemmProb> gParentSyrk;        // fused path: fronts of the leaves' parents straight from the children's Ut
-    DevVec<GemmSeg> parentSegs;
-    DevVec<FrontProb> gParentFront;      // the same nodes for k_parent_front (SYRK + factorisation in one launch)
-    int parent_front_nacc = 0;           // 0: not available (front too large for the register-resident SYRK)
-    size_t parent_front_lds = 0;
-    bool parent_syrk = false, direct_parent = false;
-    bool shape_regular = false;          // every leaf sits on the last level (all other levels hold non-leaf nodes only)
-    std::vector<AsmChild> hKids;         // host copies: the leaves' Gt blocks are allocated only when something needs them
-    std::vector<int> kid_leaf;
-    std::vector<GemmProb> hLeafSyrk;
-    int leaf_max_tiles_full = 0, leaf_max_tiles_lik = 0;
-    DevVec<AsmChild> asmKids;
-    long leaf_max_rows = 0;
-    int leaf_max_nop = 0, leaf_max_na = 0, leaf_max_ht = 0;
-    double fl_leaf_resid = 0, fl_leaf_chol = 0, fl_leaf_chol_lik = 0, fl_leaf_syrk = 0, fl_leaf_update = 0;
-    // fused ("regular tree") path
-    bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true, leaf_gemm_update = false;
-    int dbg = 0;
-    int NL = 0, CWT = 0;
-    struct FusedLevel {
-        DevVec<double> kx, Wk;
-        DevVec<int> kvalid, kt_rows, kt_chain, kt_knot0, kt_wgn;
-        DevVec<GemmProb> gKinv;
-        DevVec<long> kt_wg0;
-        long n_ktiles = 0, n_kwg = 0;
-        int k_threads = 256;        // workgroup size of the level's knot launch (512 when sibling families share a workgroup)
-    };
-    std::vector<FusedLevel> fl;
-    DevVec<long> ft_row0, ft_wg0, ft_wg0_x;
-    DevVec<int> ft_chain, ft_wgn, ft_wgn_x;
-    long n_ftiles = 0, n_fwg = 0, n_fwg_x = 0;
-    size_t cascade_lds = 0, cascade_lds_all = 0;
-    bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
-    bool cascade_group_siblings = false;
-    int n_cu = 256;
-    // knot pass of all levels in one launch (k_knot_chain)
-    bool use_knot_chain = true, knot_chain_ok = false;
-    int kc_levels = 0;                    // levels 0 .. kc_levels-1 go through the chain kernel
-    size_t knot_chain_lds = 0;
-    DevVec<int> kc_chain;                 // [bottom slot][8]
-    std::vector<DevVec<int>> kc_owner;    // per level [slot] -> owning workgroup
-    int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels (4 or 8; 4 measured faster)
-    DevVec<long> ft_wg0_leaf;
-    DevVec<int> ft_wgn_leaf;
-    long n_fwg_leaf = 0;
-    // host cov staging (MRA_KERNEL_HOST)
-    std::vector<long> cov_off;           // per node offset into covsrc
-    std::vector<double> cov_host, covdiag_host;
-    // results
-    double res_d = 0, res_u = 0;
-    // timers
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    double phase_ms[5] = {0, 0, 0, 0, 0};
-    bool ktiming = false;
-    struct KStat { int launches = 0; double ms = 0, flops = 0; } kstat[KF_COUNT];
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> kev;
-    // comm
-    void* rccl = nullptr;
-    ncclComm_t comm = nullptr;
-    ncclResult_t (*allreduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    int n_ranks = 1, rank = 0;
-    bool pass_open = false;              // a pass was started and has not reached finish_run (error or abandoned split)
-};
 
 static int fail(mra_plan* p, const MraError& e) {
     if (p) p->err = e.msg;
@@ -311,6 +52,11 @@ static void build_static(mra_plan* pl) {
     pl->node_level.assign(pl->n_nodes, 0);
     for (int m = 0; m < L; ++m)
         for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1]; ++i) pl->node_level[i] = m;
+    pl->anc_rank.assign(pl->n_nodes, 0);
+    for (int i = 0; i < pl->n_nodes; ++i) {             // nodes are numbered level by level: a parent precedes its children
+        const int pa = pl->parent[i];
+        if (pa >= 0 && pa < i) pl->anc_rank[i] = pl->anc_rank[pa] + (pl->knot_ptr[pa + 1] - pl->knot_ptr[pa]);
+    }
     for (int i = 0; i < pl->n_nodes; ++i) {
         if ((pl->row0[i] % 16) || (pl->row1[i] % 16) || pl->row1[i] < pl->row0[i] || pl->row1[i] > pl->P)
             throw MraError(MRA_ERR_INVALID, "node row ranges must be 16-aligned and inside [0,P)");
@@ -427,32 +173,34 @@ static void build_static(mra_plan* pl) {
             g.XA = pl->X.p + r0 * pl->d; g.XB = pl->X.p;
             g.M = (int)nr; g.N = lv.cw; g.K = Kanc; g.lower = 0;
             resid[s] = g;
-            lv.fl_resid += 2.0 * nr * lv.cw * Kanc;
+            const double rkt = (double)rk, anct = (double)pl->anc_rank[i], nat = anct + 1.0;      // true rank, true ancestor columns, + y
+            lv.fl_resid += Work(2.0 * nr * rkt * anct, 2.0 * nr * lv.cw * Kanc, 8.0 * nr * (Kanc + lv.cw + pl->d));
             kinv[s] = KinvProb{Lp, pl->knots_dev.p + pl->knot_ptr[i], (int)rk, lv.cw};
             pch[s] = PanelProb{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt, lv.cwt, i};
-            lv.fl_pchol += (double)lv.cw * lv.cw * lv.cw / 3.0;
+            lv.fl_pchol += Work(rkt * rkt * rkt / 3.0, (double)lv.cw * lv.cw * lv.cw / 3.0, 8.0 * 2 * lv.cw * lv.cw);
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
             tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
-            lv.fl_trsm += (double)nr * lv.cw * lv.cw;
+            lv.fl_trsm += Work((double)nr * rkt * rkt, (double)nr * lv.cw * lv.cw, 8.0 * 2 * nr * lv.cw);
             t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
             fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
-            lv.fl_fchol += (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw;
+            lv.fl_fchol += Work(rkt * rkt * rkt / 3.0 + nat * rkt * rkt, (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw,
+                                8.0 * (2.5 * lv.nf * (lv.nf + 1) / 2));      // four children's Schur blocks in (lower halves; fewer for ragged trees), the front out
             GemmProb sc{};
             sc.A = F + (size_t)lv.cw * lv.nf; sc.lda = lv.nf; sc.B = sc.A; sc.ldb = lv.nf;
             sc.C = F + (size_t)lv.cw * lv.nf + lv.cw; sc.ldc = lv.nf;
             sc.M = lv.na; sc.N = lv.na; sc.K = lv.cw; sc.lower = 1;
             schur[s] = sc;
-            lv.fl_schur += (double)lv.na * lv.na * lv.cw;
+            lv.fl_schur += Work(nat * nat * rkt, (double)lv.na * lv.na * lv.cw, 0.0);
             GemmProb u{};
             u.A = pl->W.p + r0 * pl->ldw + lv.c0; u.lda = pl->ldw;
             u.B = F + (size_t)lv.cw * lv.nf; u.ldb = lv.nf;
             u.C = pl->W.p + r0 * pl->ldw + lv.a0; u.ldc = pl->ldw;
             u.M = (int)nr; u.N = lv.na; u.K = lv.cw; u.lower = 0;
             upd[s] = u;
-            lv.fl_update += 2.0 * nr * lv.na * lv.cw;
+            lv.fl_update += Work(2.0 * nr * nat * rkt, 2.0 * nr * lv.na * lv.cw, 8.0 * 2 * nr * lv.na);
             AsmProb a{};
             a.F = F; a.nf = lv.nf; a.cw = lv.cw; a.child0 = (int)kids.size();
             a.nchild = pl->child_ptr[i + 1] - pl->child_ptr[i]; a.add_identity = 1;
@@ -697,7 +445,8 @@ static void build_leaf(mra_plan* pl, const double* y) {
     std::vector<PanelProb> pf(nl), pk(nl), pc(nl);
     std::vector<Trsm2Prob> tf(nl), tk(nl);
     pl->leaf_max_tiles_full = pl->leaf_max_tiles_lik = 0;
-    pl->fl_leaf_resid = pl->fl_leaf_chol = pl->fl_leaf_chol_lik = pl->fl_leaf_syrk = pl->fl_leaf_update = 0;
+    pl->fl_leaf_resid = pl->fl_leaf_chol = pl->fl_leaf_chol_lik = pl->fl_leaf_syrk = pl->fl_leaf_update = pl->fl_leaf_c_only = Work();
+    pl->by_leaf_ut = pl->by_leaf_tt = pl->by_leaf_c = 0;
     for (size_t t = 0; t < nl; ++t) {
         const int i = pl->leaf_nodes[t];
         const int m = pl->node_level[i];
@@ -725,7 +474,10 @@ static void build_leaf(mra_plan* pl, const double* y) {
             c.M = nop; c.N = nop; c.K = Kanc; c.lower = 1; c.sym_diag = 1; c.diag_add = pl->R;
             grl[t] = c;
         }
-        pl->fl_leaf_resid += 2.0 * nr * nop * Kanc;
+        const double no = (double)nobs[t], anct = (double)pl->anc_rank[i], nat = anct + 1.0;      // true sizes: observations, ancestor columns, + y
+        pl->by_leaf_ut += 8.0 * na * nop; pl->by_leaf_tt += 8.0 * nr * nop; pl->by_leaf_c += 8.0 * nop * nop;
+        pl->fl_leaf_resid += Work(2.0 * nr * no * anct, 2.0 * nr * nop * Kanc, 8.0 * (nr * (Kanc + pl->d) + (double)nr * nop + (double)nop * nop));
+        pl->fl_leaf_c_only += Work(no * no * anct, (double)nop * nop * Kanc, 8.0 * (no * (Kanc + pl->d) + (double)nop * nop));
         double* inv = pl->leafInv.p + pl->leaf_ioff[t];
         pf[t] = PanelProb{Pn, inv, nop, (int)((nop + na + nr) / 16), nop / 16, i};
         pk[t] = PanelProb{Pn, inv, nop, (nop + na) / 16, nop / 16, i};
@@ -734,19 +486,21 @@ static void build_leaf(mra_plan* pl, const double* y) {
         tk[t] = Trsm2Prob{Pn, inv, Pn + (size_t)nop * nop, nullptr, nop, nop, nop / 16, na / 16, 0, 1.0, q.obs, pl->W.p + a0, pl->ldw, na / 16};
         pl->leaf_max_tiles_full = std::max(pl->leaf_max_tiles_full, (int)((na + nr) / 16));
         pl->leaf_max_tiles_lik = std::max(pl->leaf_max_tiles_lik, na / 16);
-        pl->fl_leaf_chol += (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop;
-        pl->fl_leaf_chol_lik += (double)nop * nop * nop / 3.0 + (double)na * nop * nop;
+        pl->fl_leaf_chol += Work(no * no * no / 3.0 + (nat + nr) * no * no, (double)nop * nop * nop / 3.0 + (double)(na + nr) * nop * nop,
+                                 8.0 * (1.5 * nop * nop + 2.0 * (na + nr) * nop + 2.0 * nr));
+        pl->fl_leaf_chol_lik += Work(no * no * no / 3.0 + nat * no * no, (double)nop * nop * nop / 3.0 + (double)na * nop * nop,
+                                     8.0 * (1.5 * nop * nop + 2.0 * na * nop));
         GemmProb s{};
         s.A = Pn + (size_t)nop * nop; s.lda = nop; s.B = s.A; s.ldb = nop;
         s.C = pl->Gt.p ? pl->Gt.p + pl->leaf_goff[t] : nullptr; s.ldc = na; s.M = na; s.N = na; s.K = nop; s.lower = 1;
         gs[t] = s;
-        pl->fl_leaf_syrk += (double)na * na * nop;
+        pl->fl_leaf_syrk += Work(nat * nat * no, (double)na * na * nop, 8.0 * na * nop);
         GemmProb u{};
         u.A = Pn + (size_t)(nop + na) * nop; u.lda = nop; u.B = Pn + (size_t)nop * nop; u.ldb = nop;
         u.C = pl->W.p + r0 * pl->ldw + a0; u.ldc = pl->ldw; u.M = (int)nr; u.N = na; u.K = nop; u.lower = 0;
         u.zc = na - MRA_YB;                  // y block: C_in = 0 (the column still holds y itself)
         gu[t] = u;
-        pl->fl_leaf_update += 2.0 * nr * na * nop;
+        pl->fl_leaf_update += Work(2.0 * nr * nat * no, 2.0 * nr * na * nop, 8.0 * ((double)nr * nop + (double)na * nop + 2.0 * nr * na));
     }
     {
         std::vector<double*> uts(nl);
@@ -905,9 +659,11 @@ static void build_leaf(mra_plan* pl, const double* y) {
 // ------------------------------------------------------------------------------------------------
 struct KTimer {
     mra_plan* pl; int fam; hipEvent_t a = nullptr, b = nullptr;
-    KTimer(mra_plan* p, int f, double flops) : pl(p), fam(f) {
+    KTimer(mra_plan* p, int f, const Work& w) : pl(p), fam(f) {
         pl->kstat[fam].launches += 1;
-        pl->kstat[fam].flops += flops;
+        pl->kstat[fam].flops += w.alg;
+        pl->kstat[fam].flops_exec += w.exec;
+        pl->kstat[fam].bytes += w.bytes;
         if (pl->ktiming) {
             hipEventCreate(&a); hipEventCreate(&b);
             hipEventRecord(a, pl->stream);
@@ -921,54 +677,12 @@ struct KTimer {
     }
 };
 
-static inline unsigned gemm_grid_x(long M, long N, bool lower_tri) {
-    const long tm = (M + 31) / 32, tn = (N + 31) / 32;
-    return (unsigned)(((lower_tri ? tm * (tm + 1) / 2 : tm * tn) + 3) / 4);
-}
-
 template <int EPI>
-// lower_tri: every problem of the batch has .lower set and M == N (direct kernel only)
 static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true, bool lower_tri = false) {
-    if (!nprob || maxM <= 0 || maxN <= 0) return;
-    const bool lds = pl->gemm_lds && allow_lds;
-    const unsigned gx = lds ? (unsigned)(((maxM + 63) / 64) * ((maxN + 63) / 64)) : gemm_grid_x(maxM, maxN, lower_tri);
-    const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
-    // 1-D grid, XCD-aware (xcd_problem_tile): gx workgroups per problem, problems rounded up to 8
-    const size_t chunk = (size_t)std::max<long>(8, ((0x7fffffffL / (long)gx) / 8) * 8);
-    for (size_t off = 0; off < nprob; off += chunk) {
-        const unsigned gy = (unsigned)std::min<size_t>(chunk, nprob - off);
-        dim3 grid(gx * (((gy + 7u) / 8u) * 8u));
-#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp, gx, gy)
-        if (lds) {
-            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 3); }
-            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 3); }
-        } else {
-            if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt, 1, 3); }
-            else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt, 2, 3); }
-        }
-#undef MRA_GEMM_LAUNCH
-    }
+    mra_launch_gemm(pl, EPI, probs, nprob, maxM, maxN, allow_lds, lower_tri);
 }
-
-// leaf-resident product (one workgroup per problem): the two big leaf GEMMs of a pass.  The residual (few column tiles, long K)
-// runs two row tiles per wave, the update (13 column tiles at C3, short K) one row tile per wave with all columns in one pass.
 template <int EPI>
-static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) {
-    if (!nprob) return;
-    const int mode = (EPI == EPI_COV) ? pl->kp.mode : 0;
-    const dim3 grid((unsigned)nprob);
-    constexpr int CT = (EPI == EPI_SUB) ? 13 : 7;
-    // COV: one row tile per wave, 8 waves, 8 column tiles per pass (leaves of up to 128 observations in one pass), 128 registers =
-    // four waves per SIMD (the Kanter taper's sin/cos need 217: two); dbg bit 32: the 2-row-tile, 4-wave, 7-column, 239-register shape
-    const bool wide = (EPI == EPI_COV) && !(pl->dbg & 32);
-#define MRA_LG_LAUNCH(D, MD) do { \
-        if (wide) hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), 1, 8, 512, (MD == 3 ? 2 : 4)>), grid, dim3(512), 0, pl->stream, probs, pl->kp); \
-        else hipLaunchKernelGGL((k_leaf_gemm<EPI, D, (EPI == EPI_COV ? MD : 0), (EPI == EPI_SUB ? 1 : 2), CT, 256, 2>), grid, dim3(256), 0, pl->stream, probs, pl->kp); \
-    } while (0)
-    if (pl->d == 1) { if (mode == 0) MRA_LG_LAUNCH(1, 0); else if (mode == 1) MRA_LG_LAUNCH(1, 1); else if (mode == 2) MRA_LG_LAUNCH(1, 2); else MRA_LG_LAUNCH(1, 3); }
-    else { if (mode == 0) MRA_LG_LAUNCH(2, 0); else if (mode == 1) MRA_LG_LAUNCH(2, 1); else if (mode == 2) MRA_LG_LAUNCH(2, 2); else MRA_LG_LAUNCH(2, 3); }
-#undef MRA_LG_LAUNCH
-}
+static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) { mra_launch_leaf_gemm(pl, EPI, probs, nprob); }
 // the leaf-resident kernel pays off for leaves with many rows and a K loop of at least a few chunks; small leaves (config 5:
 // 64 rows, 32 observations) keep the 64x64-tile kernel
 static bool leaf_gemm_ok(const mra_plan* pl) { return pl->use_leaf_gemm && pl->leaf_max_rows >= 128 && pl->leaf_max_nop >= 64; }
@@ -980,16 +694,10 @@ static void launch_panel(mra_plan* pl, const PanelProb* probs, size_t nprob, int
 
 // row-tile triangular solve with L in LDS; returns false when nt is too large for the LDS path
 static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int nt, long max_tiles, int tiles_per_wg) {
-    if (!nprob || max_tiles <= 0 || nt <= 0) return true;
+    if (!pl->prepare_only && (!nprob || max_tiles <= 0 || nt <= 0)) return true;
     if (nt > 12) return false;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {       // dynamic LDS above 64 KiB has to be requested per kernel
-        hipFuncSetAttribute((const void*)k_trsm_rows2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_trsm_rows2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_trsm_rows2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_trsm_rows2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_attr_set = true;
-    }
+    ensure_big_lds(pl, {(const void*)k_trsm_rows2<2>, (const void*)k_trsm_rows2<4>, (const void*)k_trsm_rows2<8>, (const void*)k_trsm_rows2<12>});
+    if (pl->prepare_only) return true;
     const size_t lds = (size_t)(nt * (nt - 1) / 2 + nt) * 2048;
     const unsigned gx = (unsigned)((max_tiles + tiles_per_wg - 1) / tiles_per_wg);
     const unsigned tb = 512;
@@ -1014,73 +722,6 @@ static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int
     return true;
 }
 
-template <int CWT, int NLMAX, int DIM, int MODE>
-static void launch_cascade_inst(mra_plan* pl, const CascadeArgs& ar) {
-    // (the row pass with twelve waves per workgroup, three per SIMD, was measured at C3: 168 registers per lane spill
-    // 264 bytes and 64 row tiles do not divide over twelve waves -- 1.44 ms against 1.29 ms with eight)
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_prior_cascade<CWT, NLMAX, DIM, MODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    if (pl->cascade_stage_all)
-        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, true>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? ar.knot_threads : 512),
-                           std::max<size_t>(pl->cascade_lds_all, 40960), pl->stream, ar, pl->kp);
-    else
-        hipLaunchKernelGGL((k_prior_cascade<CWT, NLMAX, DIM, MODE, false>), dim3((unsigned)ar.n_wg), dim3(ar.knot_mode ? ar.knot_threads : 64 * pl->cascade_wpw),
-                           std::max<size_t>(pl->cascade_lds, 40960), pl->stream, ar, pl->kp);
-}
-template <int CWT, int NLMAX>
-static void launch_cascade(mra_plan* pl, const CascadeArgs& ar) {
-    if (ar.n_wg <= 0) return;
-    const int mode = pl->kp.mode;
-    if (pl->d == 1) {
-        if (mode == 0) launch_cascade_inst<CWT, NLMAX, 1, 0>(pl, ar);
-        else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 1, 1>(pl, ar);
-        else if (mode == 2) launch_cascade_inst<CWT, NLMAX, 1, 2>(pl, ar);
-        else launch_cascade_inst<CWT, NLMAX, 1, 3>(pl, ar);
-    } else {
-        if (mode == 0) launch_cascade_inst<CWT, NLMAX, 2, 0>(pl, ar);
-        else if (mode == 1) launch_cascade_inst<CWT, NLMAX, 2, 1>(pl, ar);
-        else if (mode == 2) launch_cascade_inst<CWT, NLMAX, 2, 2>(pl, ar);
-        else launch_cascade_inst<CWT, NLMAX, 2, 3>(pl, ar);
-    }
-}
-static void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) {
-    if (pl->CWT == 1) launch_cascade<1, 8>(pl, ar);
-    else if (pl->CWT == 2) launch_cascade<2, 8>(pl, ar);
-    else launch_cascade<4, 4>(pl, ar);
-}
-
-template <int CWT, int NLMAX, int DIM, int MODE>
-static void launch_knot_chain_inst(mra_plan* pl, const KnotChainArgs& ka) {
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k_knot_chain<CWT, NLMAX, DIM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_knot_chain<CWT, NLMAX, DIM, MODE>), dim3((unsigned)pl->lev[ka.nl - 1].nodes.size()), dim3(256), pl->knot_chain_lds,
-                       pl->stream, ka, pl->kp);
-}
-template <int CWT, int NLMAX>
-static void launch_knot_chain_cw(mra_plan* pl, const KnotChainArgs& ka) {
-    const int mode = pl->kp.mode;
-    if (pl->d == 1) {
-        if (mode == 0) launch_knot_chain_inst<CWT, NLMAX, 1, 0>(pl, ka);
-        else if (mode == 1) launch_knot_chain_inst<CWT, NLMAX, 1, 1>(pl, ka);
-        else if (mode == 2) launch_knot_chain_inst<CWT, NLMAX, 1, 2>(pl, ka);
-        else launch_knot_chain_inst<CWT, NLMAX, 1, 3>(pl, ka);
-    } else {
-        if (mode == 0) launch_knot_chain_inst<CWT, NLMAX, 2, 0>(pl, ka);
-        else if (mode == 1) launch_knot_chain_inst<CWT, NLMAX, 2, 1>(pl, ka);
-        else if (mode == 2) launch_knot_chain_inst<CWT, NLMAX, 2, 2>(pl, ka);
-        else launch_knot_chain_inst<CWT, NLMAX, 2, 3>(pl, ka);
-    }
-}
-static void launch_knot_chain(mra_plan* pl, const KnotChainArgs& ka) {
-    if (pl->CWT == 1) launch_knot_chain_cw<1, 8>(pl, ka);
-    else if (pl->CWT == 2) launch_knot_chain_cw<2, 8>(pl, ka);
-    else launch_knot_chain_cw<4, 4>(pl, ka);
-}
-
 // whole prior of a regular tree: per level a tiny knot pass (knot rows cascade -> kInv -> Cholesky),
 // then ONE cascade over all leaf row tiles that writes W once
 static double kernel_cov0(const mra_plan* pl) { return pl->kp.amp; }   // C(x,x) of every stationary kernel: amp * 1
@@ -1097,7 +738,7 @@ static void run_prior_fused(mra_plan* pl) {
     base.X = pl->X.p; base.W = pl->W.p; base.ldw = pl->ldw;
     const int n_chain = (pl->use_knot_chain && pl->knot_chain_ok && pl->kc_levels >= 2) ? pl->kc_levels : 0;
     if (n_chain) {
-        double fl = 0;
+        Work fl;
         for (int m = 0; m < n_chain; ++m) fl += pl->lev[m].fl_pchol;
         KTimer kt(pl, KF_PRIOR_CHOL, fl);
         KnotChainArgs ka{};
@@ -1124,8 +765,10 @@ static void run_prior_fused(mra_plan* pl) {
         launch_cascade_any(pl, ar);
     }
     {
-        double fl = 0;
+        Work fl;
         for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_resid + pl->lev[m].fl_trsm;
+        // one pass: coordinates and y in, W (all levels + y block) and the prior variance out, observed rows once more into Ut
+        fl.bytes = 8.0 * pl->P * (pl->d + 1 + pl->ldw + 1) + pl->by_leaf_ut;
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.dbg = pl->dbg;
@@ -1149,28 +792,6 @@ static void run_prior_fused(mra_plan* pl) {
     }
 }
 
-// MINB workgroups per CU: three when both the LDS image and the register budget (168 with three waves per SIMD) allow it
-template <int CWT, int NLMAX, int WPW, int MINB>
-static void launch_predict_cascade_w(mra_plan* pl, const PredArgs& ar, size_t lds) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, false, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_predict_cascade<CWT, NLMAX, WPW, true, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    if (ar.leaf_upd) hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, true, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
-    else hipLaunchKernelGGL((k_predict_cascade<CWT, NLMAX, WPW, false, MINB>), dim3((unsigned)ar.n_wg), dim3(64 * WPW), lds, pl->stream, ar);
-}
-template <int CWT, int NLMAX>
-static void launch_predict_cascade(mra_plan* pl, const PredArgs& ar, size_t lds) {
-    if (pl->cascade_wpw == 8) launch_predict_cascade_w<CWT, NLMAX, 8, 1>(pl, ar, lds);
-    else if (pl->cascade_wpw == 4) {
-        if (CWT <= 2 && NLMAX <= 6 && 3 * lds <= 160 * 1024 && !(pl->dbg & 8)) launch_predict_cascade_w<CWT, NLMAX, 4, (CWT <= 2 && NLMAX <= 6) ? 3 : 2>(pl, ar, lds);
-        else launch_predict_cascade_w<CWT, NLMAX, 4, 2>(pl, ar, lds);
-    }
-    else throw MraError(MRA_ERR_STATE, "cascade_wpw must be 4 or 8");
-}
-
 static void run_predict_fused(mra_plan* pl) {
     PredArgs ar{};
     for (int m = 0; m < pl->NL; ++m) {
@@ -1183,14 +804,15 @@ static void run_predict_fused(mra_plan* pl) {
     ar.n_wg = pl->n_fwg_x; ar.nl = pl->NL;
     const int cwt = pl->CWT, mmax = pl->NL - 1;
     size_t lds = (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax * cwt + 1) * cwt) * 2048;
-    double fl = 0;
+    Work fl;
     for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
+    fl.bytes = 8.0 * pl->P * (pl->ldw + 3);                // W once in, var in/out, mean out (the level operands stay in L2)
     if (pl->pred_update_now) {
         // the leaf update rides in this launch (two Ut chunk stages share the LDS with the level operands)
         ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
         ar.leaf_upd = pl->leaf_upd_dev.p; ar.na = pl->na[pl->NL];
         lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 128) * sizeof(double));      // two 8-k chunks of Ut
-        fl += pl->fl_leaf_update;
+        fl += Work(pl->fl_leaf_update.alg, pl->fl_leaf_update.exec, pl->by_leaf_tt + pl->by_leaf_ut);    // Tt and Ut in, nothing out
     }
 #ifdef MRA_STAMPS
     if (!pl->pstamps.p) { pl->pstamps.alloc((size_t)pl->n_ftiles * 16); HIP_TRY(mraMemset(pl->pstamps.p, 0, pl->pstamps.n * sizeof(double))); }
@@ -1198,9 +820,7 @@ static void run_predict_fused(mra_plan* pl) {
 #endif
     KTimer kt(pl, KF_PRED_UPDATE, fl);
     if (ar.n_wg <= 0) return;
-    if (cwt == 1) launch_predict_cascade<1, 8>(pl, ar, lds);
-    else if (cwt == 2) { if (pl->NL <= 6) launch_predict_cascade<2, 6>(pl, ar, lds); else launch_predict_cascade<2, 8>(pl, ar, lds); }
-    else launch_predict_cascade<4, 4>(pl, ar, lds);
+    launch_predict_any(pl, ar, lds);
 }
 
 // events 0 and 5 bracket every pass; the four inner phase boundaries are recorded only with kernel timing on
@@ -1214,12 +834,7 @@ static bool run_front_fused(mra_plan* pl, int m, bool do_assemble, bool add_iden
     const size_t nn = lv.nodes.size();
     if (!nn) return true;
     if (!pl->use_front_fused || lv.front_mode == 0 || (do_assemble && lv.front_mode != 2)) return false;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)k_front<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute((const void*)k_front<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    ensure_big_lds(pl, {(const void*)k_front<true>, (const void*)k_front<false>});
     KTimer kt(pl, KF_FRONT_CHOL, lv.fl_fchol + lv.fl_schur);
     if (lv.front_mode == 2)
         hipLaunchKernelGGL(k_front<true>, dim3((unsigned)nn), dim3(512), lv.front_lds, pl->stream, lv.gFront.p, pl->asmKids.p,
@@ -1268,15 +883,8 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 const LevelData& lvp = pl->lev[m];
                 if (pl->use_front_fused && pl->parent_front_nacc > 0) {
                     // children's Ut -> front -> Lt, Zt, Schur block, all in one launch (the front never visits HBM unfactorised)
-                    static bool attr = false;
-                    if (!attr) {
-                        hipFuncSetAttribute((const void*)k_parent_front<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        hipFuncSetAttribute((const void*)k_parent_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        hipFuncSetAttribute((const void*)k_parent_front<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        hipFuncSetAttribute((const void*)k_parent_front<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        attr = true;
-                    }
-                    KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk + lvp.fl_fchol + lvp.fl_schur);
+                    ensure_big_lds(pl, {(const void*)k_parent_front<2>, (const void*)k_parent_front<4>, (const void*)k_parent_front<8>, (const void*)k_parent_front<12>});
+                    KTimer kt(pl, KF_LEAF_SYRK, (pl->fl_leaf_syrk + lvp.fl_fchol + lvp.fl_schur).with_bytes(pl->by_leaf_ut + 8.0 * lvp.nodes.size() * (0.5 * lvp.nf * (lvp.nf + 1))));
                     const dim3 grid((unsigned)lvp.nodes.size());
                     const size_t lds = pl->parent_front_lds;
                     switch (pl->parent_front_nacc) {
@@ -1480,7 +1088,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     if (nl) {
         const bool c_only = !pred && fused && pl->gemm_lds && pl->leaf_max_nop / 16 <= 12;
         {
-            KTimer kt(pl, KF_LEAF_RESID, c_only ? 0.0 : pl->fl_leaf_resid);
+            KTimer kt(pl, KF_LEAF_RESID, c_only ? pl->fl_leaf_c_only : pl->fl_leaf_resid);
             if (pl->host_cov) {
                 if (leaf_gemm_ok(pl)) launch_leaf_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl);
                 else launch_gemm<EPI_HOSTCOV>(pl, pl->gLeafResid.p, nl, pl->leaf_max_rows, pl->leaf_max_nop);
@@ -1583,11 +1191,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             } else if (solve_fused) {
                 // Tt = V Lc^-T, var -= |Tt|^2 and W -= Tt Ut^T in one launch for the leaves with <= 8 observation tiles; the few
                 // larger ones went through the full row solve above and take the plain update product
-                static bool attr = false;
-                if (!attr) {
-                    hipFuncSetAttribute((const void*)k_leaf_solve_update<8, 13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    attr = true;
-                }
+                ensure_big_lds(pl, {(const void*)k_leaf_solve_update<8, 13, true>});
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
                 const size_t ns = pl->n_trsm_small;
                 hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p);
@@ -1932,8 +1536,65 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
     if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
     if (option == 8) { pl->use_pred_update = value != 0; return MRA_OK; }
-    if (option == 99) { pl->dbg = (int)value; return MRA_OK; }          // what-if timing switches of the prior row cascade (wrong results)
+    if (option == 99) {
+        // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
+        // wide leaf-residual shape); bits 1, 2, 4 (no Ut scatter / no W stores / constant instead of the kernel) give WRONG results
+        // and exist only in the diagnostic what-if build (`make whatif`, -DMRA_WHATIF): the product library refuses them.
+#ifdef MRA_WHATIF
+        pl->dbg = (int)value;
+#else
+        if (value & ~(int64_t)(8 | 32)) return fail(pl, MraError(MRA_ERR_INVALID, "option 99: bits other than 8 and 32 need the -DMRA_WHATIF diagnostic build"));
+        pl->dbg = (int)value;
+#endif
+        return MRA_OK;
+    }
     return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
+}
+
+int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
+    if (!pl || !value) return MRA_ERR_INVALID;
+    switch (option) {
+        case 1: *value = pl->ktiming; break;
+        case 2: *value = pl->use_fused; break;
+        case 3: *value = pl->gemm_lds; break;
+        case 4: *value = pl->use_front_fused; break;
+        case 5: *value = pl->use_knot_chain; break;
+        case 6: *value = pl->use_leaf_gemm ? (pl->leaf_gemm_update ? 2 : 1) : 0; break;
+        case 7: *value = pl->leaf_solve_mode; break;
+        case 8: *value = pl->use_pred_update; break;
+        case 99: *value = pl->dbg; break;
+        default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
+    }
+    return MRA_OK;
+}
+
+// Raise the dynamic-LDS limit of every kernel this plan can launch on ITS device now instead of at first launch (the
+// attribute is per device and per kernel; plans on different devices each do it).  n_kernels: how many kernels are on record.
+int mra_plan_prepare(mra_plan* pl, int64_t* n_kernels) {
+    if (!pl) return MRA_ERR_INVALID;
+    try {
+        HIP_TRY(mraSetDevice(pl->device));
+        pl->prepare_only = true;
+        struct Guard { mra_plan* p; ~Guard() { p->prepare_only = false; } } guard{pl};
+        launch_trsm2(pl, nullptr, 0, 1, 0, 1);
+        ensure_big_lds(pl, {(const void*)k_front<true>, (const void*)k_front<false>, (const void*)k_parent_front<2>, (const void*)k_parent_front<4>,
+                            (const void*)k_parent_front<8>, (const void*)k_parent_front<12>, (const void*)k_leaf_solve_update<8, 13, true>});
+        if (pl->regular) {
+            CascadeArgs ar{};
+            ar.n_wg = 1;
+            launch_cascade_any(pl, ar);
+            KnotChainArgs ka{};
+            ka.nl = 1;
+            launch_knot_chain(pl, ka);
+            PredArgs pa{};
+            pa.n_wg = 1;
+            launch_predict_any(pl, pa, 0);
+            pa.leaf_upd = (const unsigned char*)1;       // never dereferenced: prepare_only returns before any launch
+            launch_predict_any(pl, pa, 0);
+        }
+        if (n_kernels) *n_kernels = (int64_t)pl->big_lds_done.size();
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
 }
 
 int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int* launches, double* ms, double* flops) {
@@ -1943,6 +1604,19 @@ int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int*
     if (launches) *launches = pl->kstat[which].launches;
     if (ms) *ms = pl->kstat[which].ms;
     if (flops) *flops = pl->kstat[which].flops;
+    return MRA_OK;
+}
+
+int mra_get_kernel_work(mra_plan* pl, int which, double* out, int cap) {
+    if (!pl || !out || which < 0 || which >= KF_COUNT) return MRA_ERR_INVALID;
+    const double v[4] = {pl->kstat[which].flops, pl->kstat[which].flops_exec, pl->kstat[which].bytes, pl->kstat[which].ms};
+    for (int k = 0; k < std::min(cap, 4); ++k) out[k] = v[k];
+    return MRA_OK;
+}
+
+int mra_device_synchronize(int device) {
+    if (g_dry) return MRA_OK;
+    if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_last_error = "hipDeviceSynchronize failed"; return MRA_ERR_HIP; }
     return MRA_OK;
 }
 
@@ -1964,6 +1638,7 @@ int mra_eval_kernel(int kind, const double* params, int n_params, const double* 
     kp.kind = kind; kp.d = 1; kp.l = params[0]; kp.sig = params[1]; kp.scale = params[2];
     kp.circular = (n_params >= 4 && params[3] != 0.0) ? 1 : 0;
     derive_kernel_params(kp);
+    if (g_dry) { g_last_error = "MRA_HOST_DRYRUN: nothing runs in this mode"; return MRA_ERR_STATE; }
     double *dD = nullptr, *dO = nullptr;
     if (mraMalloc((void**)&dD, n * sizeof(double)) != hipSuccess || mraMalloc((void**)&dO, n * sizeof(double)) != hipSuccess) {
         g_last_error = "hipMalloc failed (no GPU?)";
@@ -1972,7 +1647,8 @@ int mra_eval_kernel(int kind, const double* params, int n_params, const double* 
     }
     mraMemcpy(dD, D, n * sizeof(double), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dD, dO, (long)n, kp);
-    hipError_t e = mraMemcpy(out, dO, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = mraMemcpy(out, dO, n * sizeof(double), hipMemcpyDeviceToHost);
     mraFree(dD); mraFree(dO);
     if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return MRA_ERR_HIP; }
     return MRA_OK;

@@ -80,6 +80,7 @@ def collect_node_blocks(tree, posterior: bool = True) -> List[NodeBlocks]:
     # ---- pass 2: posterior, level-by-level kernels (they write every level's X back into W)
     Wx = front = None
     if posterior:
+        was_fused = pl.get_option(P.MRA_OPT_FUSED)           # the caller's setting comes back afterwards, whatever it was
         pl.set_option(P.MRA_OPT_FUSED, 0)
         try:
             pl.run(True, True)
@@ -87,7 +88,7 @@ def collect_node_blocks(tree, posterior: bool = True) -> List[NodeBlocks]:
             dnode = pl.buffer(1)
             front = {i: pl.node_block(i, P.MRA_BLOCK_FRONT) for i in range(n) if not topo.node_leaf[i]}
         finally:
-            pl.set_option(P.MRA_OPT_FUSED, 1)
+            pl.set_option(P.MRA_OPT_FUSED, was_fused)
 
     def chain_of(i):
         c = []
@@ -173,13 +174,19 @@ def collect_node_blocks(tree, posterior: bool = True) -> List[NodeBlocks]:
             else:
                 yo = np.where(topo.perm[pr] >= 0, yv[topo.perm[pr]], np.nan)
                 o = np.isfinite(yo)
-                Bo = nb.B[o]
-                Amm = Bo.T @ Bo / R
-                nb.A = Amm
-                nb.omg = Bo.T @ yo[o] / R
+                # the same A[k][l] / omg[k] structure as every other node (MRANode.py:415-430): B^k = rows of ancestor k's
+                # prior basis for this leaf (_getB_lk, :346-355), B^m = the leaf's own
+                Bk = []
+                for a in anc:
+                    ma, ra = int(topo.node_level[a]), topo.rank(a)
+                    Bk.append(Wp[pr, coff[ma]:coff[ma] + ra] @ Lp[a][:ra, :ra].T)
+                Bk.append(nb.B)
+                nb.A = [[Bk[k][o].T @ Bk[l][o] / R for l in range(m + 1)] for k in range(m + 1)]
+                nb.omg = [Bk[k][o].T @ yo[o] / R for k in range(m + 1)]
+                Amm = nb.A[m][m]
                 nb.kTil = np.linalg.inv(nb.kInv + Amm)
                 nb.BTil = nb.B
-                nb.u = float(-nb.omg @ nb.kTil @ nb.omg + yo[o] @ yo[o] / R)
+                nb.u = float(-nb.omg[m] @ nb.kTil @ nb.omg[m] + yo[o] @ yo[o] / R)
             ev, V = np.linalg.eigh(0.5 * (nb.kTil + nb.kTil.T))            # MRANode.py:504-507
             nb.kTilC = V @ np.diag(np.sqrt(np.abs(ev)))
             nb.d = float(sub_d[i])

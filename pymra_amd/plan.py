@@ -35,8 +35,8 @@ ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4
 EXPORTS = [
     "mra_device_count", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
     "mra_plan_set_kernel", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
-    "mra_get_buffer", "mra_get_node_block", "mra_get_timers", "mra_plan_set_option", "mra_kernel_family_count",
-    "mra_get_kernel_stats", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
+    "mra_get_buffer", "mra_get_node_block", "mra_get_timers", "mra_plan_set_option", "mra_plan_get_option", "mra_plan_prepare", "mra_kernel_family_count",
+    "mra_get_kernel_stats", "mra_get_kernel_work", "mra_device_synchronize", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
     "mra_run_resume", "mra_last_error", "mra_version",
     "mra_tree_replay_2d", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
@@ -87,8 +87,12 @@ def load_library():
         "mra_get_node_block": (C.c_int, [vp, i32, C.c_int, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "mra_get_timers": (C.c_int, [vp, vp, C.c_int]),
         "mra_plan_set_option": (C.c_int, [vp, C.c_int, i64]),
+        "mra_plan_get_option": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
+        "mra_plan_prepare": (C.c_int, [vp, C.POINTER(i64)]),
         "mra_kernel_family_count": (C.c_int, []),
         "mra_get_kernel_stats": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(dbl), C.POINTER(dbl)]),
+        "mra_get_kernel_work": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+        "mra_device_synchronize": (C.c_int, [C.c_int]),
         "mra_plan_info": (C.c_int, [vp, vp, C.c_int]),
         "mra_comm_unique_id": (C.c_int, [C.c_char_p, C.c_int]),
         "mra_comm_init": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
@@ -234,6 +238,17 @@ class HipPlan:
     def set_option(self, option, value):
         self._check(self.lib.mra_plan_set_option(self._h, int(option), int(value)))
 
+    def get_option(self, option):
+        v = C.c_int64()
+        self._check(self.lib.mra_plan_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
+
+    def prepare(self):
+        """Raise the dynamic-LDS limits of this plan's kernels on its device now; returns how many kernels are on record."""
+        n = C.c_int64()
+        self._check(self.lib.mra_plan_prepare(self._h, C.byref(n)))
+        return int(n.value)
+
     # -- run / results -----------------------------------------------------------------------------
     def run(self, likelihood=True, predict=True, split=False):
         flags = (MRA_RUN_LIKELIHOOD if likelihood else 0) | (MRA_RUN_PREDICT if predict else 0) | (MRA_RUN_SPLIT if split else 0)
@@ -289,7 +304,9 @@ class HipPlan:
             name = C.create_string_buffer(128)
             n, ms, fl = C.c_int(), C.c_double(), C.c_double()
             self._check(self.lib.mra_get_kernel_stats(self._h, k, name, 128, C.byref(n), C.byref(ms), C.byref(fl)))
-            res.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value))
+            w = np.zeros(4)
+            self._check(self.lib.mra_get_kernel_work(self._h, k, _ptr(w), 4))
+            res.append(dict(name=name.value.decode(), launches=n.value, ms=ms.value, flops=fl.value, flops_exec=float(w[1]), bytes=float(w[2])))
         return res
 
     def info(self):
@@ -340,3 +357,10 @@ def eval_kernel(kind, l, sig, scale, D):
 
 def device_count() -> int:
     return int(load_library().mra_device_count())
+
+
+def device_synchronize(device: int = 0) -> None:
+    """hipDeviceSynchronize on `device` through the library (no other GPU runtime needed for a barrier)."""
+    rc = load_library().mra_device_synchronize(int(device))
+    if rc != 0:
+        raise MraError(rc, "hipDeviceSynchronize failed")

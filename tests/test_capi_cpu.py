@@ -61,3 +61,39 @@ def test_cov_probe_recognises_device_kernels():
     v = mt.Matern32(x, x, l=0.3, sig=2.0)
     assert isinstance(v, np.matrix) and v.shape == (5, 5) and abs(v[0, 0] - 2.0) < 1e-15
     assert np.allclose(np.asarray(s.evaluate(x, x)), 2.5 * np.asarray(mt.Matern32(x, x, l=0.3, sig=1.5)))
+
+
+def test_every_plan_raises_its_own_lds_limits(built_library, tmp_path):
+    """The 160 KB dynamic-LDS attribute is per kernel AND per device: it is recorded per plan (a plan lives on one device),
+    not behind a process-wide flag - two plans on different device ordinals in one process both take the path.  Host dry
+    run (MRA_HOST_DRYRUN=1: plans are built in host memory, nothing is launched), so this runs without a GPU."""
+    import subprocess
+    import sys
+    child = tmp_path / "child.py"
+    child.write_text(r'''
+import os, sys
+sys.path.insert(0, os.environ["MRA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MRA_ROOT"], "tests"))
+import _cases as K
+import pymra_amd.MRATools as mt
+from pymra_amd import plan as P
+cs = K.load_case("g64")
+counts = []
+for dev in (0, 1, 0):
+    pl = P.HipPlan(cs["topo"], dev)
+    pl.set_locs(cs["locs"]); pl.set_obs(cs["y_obs"], cs["c"]["R"]); pl.set_kernel(mt.KIND_EXP, 0.3, 1.0, 1.0)
+    counts.append(pl.prepare())
+    assert pl.prepare() == counts[-1]            # idempotent
+    try:
+        pl.set_option(99, 2)                     # what-if bits that change results are not in the product library
+        raise SystemExit("option 99 bit 2 must be refused")
+    except P.MraError as e:
+        assert e.code == -1
+    pl.set_option(99, 8); assert pl.get_option(99) == 8
+    pl.set_option(P.MRA_OPT_FUSED, 0); assert pl.get_option(P.MRA_OPT_FUSED) == 0
+    pl.close()
+print("LDS_ATTR_OK", counts)
+assert counts[0] >= 10 and counts[0] == counts[1] == counts[2]
+''')
+    env = dict(os.environ, MRA_ROOT=K.ROOT, MRA_HOST_DRYRUN="1")
+    res = subprocess.run([sys.executable, str(child)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "LDS_ATTR_OK" in res.stdout, (res.stdout + res.stderr)[-2000:]

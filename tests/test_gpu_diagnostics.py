@@ -37,8 +37,8 @@ def test_node_blocks_match_the_reference(built_library, name):
         assert np.max(np.abs(nb.kInv - g["kInv"])) < 1e-9
         assert np.max(np.abs(nb.kC @ nb.kC.T - g["kC"] @ g["kC"].T)) < 1e-7 * sc(g["kC"]) ** 2
         assert np.max(np.abs(nb.kTil - g["kTil"])) < 1e-7 * sc(g["kTil"]), nb.ID
-        Amm = nb.A if nb.leaf else nb.A[nb.res][nb.res]
-        omg = nb.omg if nb.leaf else nb.omg[nb.res]
+        Amm = nb.A[nb.res][nb.res]                 # leaves carry the same A[k][l] / omg[k] structure as every node
+        omg = nb.omg[nb.res]
         assert np.max(np.abs(Amm - g["Amm"])) < 1e-8 * sc(g["Amm"]), nb.ID
         assert np.max(np.abs(omg - g["omg"])) < 1e-8 * sc(g["omg"]), nb.ID
         assert np.max(np.abs(nb.BTil - g["BTil"])) < 1e-8, nb.ID

@@ -1,0 +1,88 @@
+"""Register / scratch budget of the kernels in the product build ("a kernel-resource report with no scratch
+is part of done").  __graft_entry__.build() compiles every translation unit with -Rpass-analysis=kernel-resource-usage and keeps
+the remarks of that very build next to the library (pymra_amd/libmra_hip.resource_usage.txt); this test parses them - no
+second compile - and fails when a kernel that a C3 / C5 pass launches uses scratch memory, or when any other kernel starts to.
+
+ALLOWED lists the known exceptions with their bound and the reason; anything else must report 0 bytes of scratch."""
+import os
+import re
+import sys
+
+import pytest
+
+import _cases as K
+
+sys.path.insert(0, os.path.join(K.ROOT, "tools"))
+
+# kernels launched by a likelihood+predict pass of BASELINE config 3 (fused path, 2-D, Matern32 = mode 0) and of config 5
+# (level-by-level path), sharded or not
+PRODUCTION = [
+    r"k_knot_chain<2, 8, 2, 0>", r"k_prior_cascade<2, 8, 2, 0, true>", r"k_leaf_gemm<2, 2, 0, 1, 8, 512, 4>",
+    r"k_chol_wave<12>", r"k_trsm_rows2<8>", r"k_trsm_rows2<12>", r"k_front<true>", r"k_leaf_solve_update<8, 13, true>",
+    r"k_gemm_nt_lds<2, 2, 0>", r"k_gemm_nt_lds<1, 2, 0>", r"k_gemm_nt<0, 2, 0>", r"k_gemm_nt<1, 2, 0>", r"k_panel_chol",
+    r"k_trsm_rows2<4>", r"k_front<false>", r"k_sum_dnode", r"k_leaf_cphantom", r"k_assemble", r"k_leaf_moments",
+]
+# (pattern, max scratch bytes per lane, reason)
+ALLOWED = [
+    # Kanter taper: ocml sin/cos (Payne-Hanek range reduction keeps a private table on the stack); not a spill
+    (r"k_prior_cascade<\d, \d, \d, 3, (true|false)>", 544, "ocml sincos stack"),
+    (r"k_knot_chain<\d, \d, \d, 3>", 544, "ocml sincos stack"),
+    (r"k_leaf_gemm<2, \d, 3,", 544, "ocml sincos stack"),
+    (r"k_gemm_nt(_lds)?<2, \d, 3>", 544, "ocml sincos stack"),
+    (r"k_eval_kernel", 544, "ocml sincos stack"),
+    # dominant kernel at three workgroups per CU (168 registers): the staging registers of the NEXT level's operands are parked
+    # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
+    # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
+    (r"k_predict_cascade<2, 6, 4, (true|false), 3>", 80, "level-operand staging parked across the level barrier"),
+    # the diagonal-block routine (chol16_inv, ~100 registers) runs beside 96 accumulator registers; the spills sit around it,
+    # once per workgroup, outside the K loop
+    (r"k_parent_front<12>", 40, "around chol16_inv, outside the K loop"),
+    # instantiations no benchmark configuration launches (CWT = 4 cascades of shallow wide trees, 8-level CWT = 2 with update)
+    (r"k_predict_cascade<4, 4, \d, (true|false), \d>", 600, "not launched by C1-C5; superseded by the two-group cascade for r0 = 64"),
+    (r"k_predict_cascade<2, 8, 4, true, 2>", 24, "7-8 level CWT = 2 trees only"),
+    (r"k_prior_cascade<4, 4, \d, \d, true>", 40, "CWT = 4 trees with <= 4 levels only"),
+]
+
+
+@pytest.fixture(scope="module")
+def usage(built_library):
+    import resource_usage
+    p = os.path.join(K.ROOT, "pymra_amd", "libmra_hip.resource_usage.txt")
+    if not os.path.exists(p):
+        pytest.skip("no resource-usage remarks next to the library (built outside __graft_entry__.build / make lib)")
+    res = resource_usage.parse(open(p).read())
+    assert len(res) > 150
+    return res
+
+
+def _find(usage, pat):
+    return {n: r for n, r in usage.items() if pat in n}
+
+
+def test_production_kernels_use_no_scratch(usage):
+    for pat in PRODUCTION:
+        hits = _find(usage, pat)
+        assert hits, "kernel %s not found in the remarks" % pat
+        for n, r in hits.items():
+            assert r["scratch"] == 0, "%s: %d B/lane of scratch, %s spilled registers" % (n, r["scratch"], r["spills"])
+
+
+def test_no_other_kernel_starts_to_spill(usage):
+    bad = []
+    for n, r in sorted(usage.items()):
+        if not r["scratch"]:
+            continue
+        lim = [b for p, b, _ in ALLOWED if re.search(p, n)]
+        if not lim or r["scratch"] > max(lim):
+            bad.append("%s: %d B/lane (%s spills)" % (n, r["scratch"], r["spills"]))
+    assert not bad, "\n".join(bad)
+
+
+def test_mfma_kernels_keep_their_accumulators_out_of_agprs(usage):
+    """With the full 512-register budget hipcc parks MFMA accumulators in AGPRs and copies them around every loop iteration
+    (DESIGN.md section 5); every MFMA kernel of the pass is cut for <= 256 registers.  The knot chain (one workgroup per CU,
+    latency-bound) is the one kernel allowed to use them."""
+    for n, r in usage.items():
+        if "k_knot_chain" in n:
+            continue
+        assert not r["agprs"], "%s uses %s AGPRs" % (n, r["agprs"])
