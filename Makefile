@@ -4,11 +4,12 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC   = pymra_amd/csrc
 UNITS  = mra_plan mra_launch_gemm mra_launch_pred mra_launch_prior_row1 mra_launch_prior_row2 mra_launch_prior_knot1 mra_launch_prior_knot2
-HDRS   = $(CSRC)/mra_kernels.h $(CSRC)/mra_plan_types.h $(CSRC)/mra_topology.h $(CSRC)/mra_launch_prior.inc include/mra_hip.h
+HDRS   = $(CSRC)/mra_kernels.h $(CSRC)/mra_plan_types.h $(CSRC)/mra_launch_prior.inc include/mra_hip.h
 CFLAGS = --offload-arch=gfx950 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -Wno-pass-failed
 B      = build
 
 lib: pymra_amd/libmra_hip.so
+$(B)/prod/mra_plan.o $(B)/asan/mra_plan.o $(B)/stamps/mra_plan.o $(B)/whatif/mra_plan.o: $(CSRC)/mra_topology.h
 $(B)/prod/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(B)/prod
 	$(HIPCC) $(CFLAGS) -O3 -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(B)/prod/$*.remarks.txt || (cat $(B)/prod/$*.remarks.txt; exit 1)

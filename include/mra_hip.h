@@ -148,6 +148,19 @@ int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int6
 int mra_get_node_block(mra_plan *plan, int32_t node, int what, double *out, int64_t capacity,
                        int64_t *n_rows, int64_t *n_cols);
 
+/* Device blocks of destroyed plans are cached per (device, size) and reused by later plans of the process - the reference's
+ * MLE pattern builds a new MRATree per objective call (README.md:96-104).  This hands every cached block back to the driver. */
+int mra_release_cached_memory(void);
+
+/* Caller-order variants of mra_plan_set_locs / mra_plan_set_obs / mra_get_predict: the arrays are in the CALLER's row order
+ * (locs N x d, y N; NaN = missing), src[P] / perm[P] / in_leaf[P] are the topology's row maps (padded row -> caller row it
+ * copies; -1 in perm for a phantom row; in_leaf = row is reported).  The gather / scatter runs inside the library (threads +
+ * a pinned staging area), which is what an end-to-end MRATree(...) call pays for instead of NumPy fancy indexing and
+ * pageable copies (MRATree.__init__, pyMRA/MRATree.py:61-69, hands the arrays over in caller order). */
+int mra_plan_set_locs_rows(mra_plan *plan, const double *locs, const int64_t *src);
+int mra_plan_set_obs_rows(mra_plan *plan, const double *y, const int64_t *src, const int64_t *perm, double R);
+int mra_get_predict_rows(mra_plan *plan, const int64_t *perm, const uint8_t *in_leaf, int64_t N, double *mean, double *var);
+
 /* Per-phase device milliseconds of the last mra_run (hipEvent deltas on the plan's stream):
  * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written.
  * The four phase entries are measured only while MRA_OPT_KERNEL_TIMING is on (0 otherwise): an event

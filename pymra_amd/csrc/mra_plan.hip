@@ -9,6 +9,68 @@
 //   4. predictive moments, bottom-up(:486-520)
 // DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
 #include "mra_plan_types.h"
+#include "mra_topology.h"
+#include <mutex>
+#include <thread>
+
+// ---- device memory cache --------------------------------------------------------------------------------------------
+#include <map>
+#include <unordered_map>
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<int, size_t>> live;           // pointer -> (device, bytes) of pooled-size blocks in use
+    std::multimap<std::pair<int, size_t>, void*> idle;                // (device, bytes) -> cached block
+    size_t idle_bytes = 0;
+    static constexpr size_t MIN_BLOCK = 256 * 1024;                   // smaller blocks are not worth keeping
+    static constexpr size_t MAX_IDLE = (size_t)64 << 30;              // cached bytes above this are returned to the driver
+    void flush_locked() {
+        for (auto& e : idle) hipFree(e.second);
+        idle.clear();
+        idle_bytes = 0;
+    }
+    ~DevPool() { /* process exit: the driver reclaims everything; calling into HIP from a static destructor is not safe */ }
+};
+DevPool g_pool;
+}  // namespace
+
+hipError_t mraMalloc(void** p, size_t n) {
+    if (g_dry) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+    if (n < DevPool::MIN_BLOCK) return hipMalloc(p, n);
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    auto it = g_pool.idle.find({dev, n});
+    if (it != g_pool.idle.end()) {
+        *p = it->second;
+        g_pool.idle.erase(it);
+        g_pool.idle_bytes -= n;
+        g_pool.live[*p] = {dev, n};
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, n);
+    if (e != hipSuccess && !g_pool.idle.empty()) {                    // out of memory with blocks cached: give them back and retry
+        (void)hipGetLastError();
+        g_pool.flush_locked();
+        e = hipMalloc(p, n);
+    }
+    if (e == hipSuccess) g_pool.live[*p] = {dev, n};
+    return e;
+}
+
+hipError_t mraFree(void* p) {
+    if (g_dry) { free(p); return hipSuccess; }
+    if (!p) return hipSuccess;
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it == g_pool.live.end()) return hipFree(p);
+    const std::pair<int, size_t> key = it->second;
+    g_pool.live.erase(it);
+    if (g_pool.idle_bytes + key.second > DevPool::MAX_IDLE) return hipFree(p);
+    g_pool.idle.insert({key, p});
+    g_pool.idle_bytes += key.second;
+    return hipSuccess;
+}
 
 static void derive_kernel_params(KernelParams& kp) {
     kp.mode = 0; kp.a1 = 0.0; kp.a2 = 0.0; kp.amp = kp.scale * kp.sig;
@@ -1215,6 +1277,32 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     run_fronts_and_predict(pl, pl->n_levels - 1, false);
 }
 
+// ---- caller-order variants: the permutation work of an end-to-end MRATree(...) call done inside the library -----------------
+// A process-wide pinned staging area (grow-only): gathers land in it, the H2D / D2H copies run at the pinned rate (a pageable
+// 16 MB copy costs ~5 ms, a pinned one ~0.7 ms), and a second plan in the same process does not pay for the allocation again.
+static std::mutex g_stage_mutex;
+static double* g_stage = nullptr;
+static size_t g_stage_n = 0;
+static double* stage_buffer(size_t n) {               // caller holds g_stage_mutex
+    if (n > g_stage_n) {
+        if (g_stage) { if (g_dry) free(g_stage); else hipHostFree(g_stage); g_stage = nullptr; g_stage_n = 0; }
+        if (g_dry) g_stage = (double*)malloc(n * sizeof(double));
+        else if (hipHostMalloc((void**)&g_stage, n * sizeof(double), hipHostMallocDefault) != hipSuccess) g_stage = nullptr;
+        if (!g_stage) throw MraError(MRA_ERR_HIP, "pinned staging allocation failed");
+        g_stage_n = n;
+    }
+    return g_stage;
+}
+template <class F>
+static void parallel_rows(int64_t n, F fn) {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::thread::hardware_concurrency()), n / 65536));
+    if (T <= 1) { fn(0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
+    for (auto& th : pool) th.join();
+}
+
+
 // ------------------------------------------------------------------------------------------------
 //  C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1293,6 +1381,9 @@ int mra_plan_destroy(mra_plan* pl) {
         destroy_t fn = (destroy_t)dlsym(pl->rccl, "ncclCommDestroy");
         if (fn) fn(pl->comm);
     }
+    // the plan's device blocks go back to the cache and may be handed to another plan at once: nothing of this plan may still run
+    if (pl->stream) hipStreamSynchronize(pl->stream);
+    if (pl->stream2) hipStreamSynchronize(pl->stream2);
     for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
     if (pl->stream) hipStreamDestroy(pl->stream);
     if (pl->stream2) hipStreamDestroy(pl->stream2);
@@ -1300,6 +1391,13 @@ int mra_plan_destroy(mra_plan* pl) {
     if (pl->ev_join) hipEventDestroy(pl->ev_join);
     if (pl->host_res) hipHostFree(pl->host_res);
     delete pl;
+    return MRA_OK;
+}
+
+int mra_release_cached_memory(void) {
+    if (g_dry) return MRA_OK;
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    g_pool.flush_locked();
     return MRA_OK;
 }
 
@@ -1326,6 +1424,49 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
             }
         }
         pl->have_locs = true;
+        return MRA_OK;
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+// ---- caller-order variants (helpers above the extern "C" block)
+int mra_plan_set_locs_rows(mra_plan* pl, const double* locs, const int64_t* src) {
+    if (!pl || !locs || !src) return MRA_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        const int d = pl->d;
+        double* xp = stage_buffer((size_t)pl->P * d);
+        parallel_rows(pl->P, [&](int64_t a, int64_t b) {
+            if (d == 2) for (int64_t p = a; p < b; ++p) { const int64_t q = src[p]; xp[2 * p] = locs[2 * q]; xp[2 * p + 1] = locs[2 * q + 1]; }
+            else for (int64_t p = a; p < b; ++p) xp[p] = locs[src[p]];
+        });
+        return mra_plan_set_locs(pl, xp);
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_plan_set_obs_rows(mra_plan* pl, const double* y, const int64_t* src, const int64_t* perm, double R) {
+    if (!pl || !y || !src || !perm) return MRA_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        double* yp = stage_buffer((size_t)pl->P);
+        const double nan = std::nan("");
+        parallel_rows(pl->P, [&](int64_t a, int64_t b) { for (int64_t p = a; p < b; ++p) yp[p] = perm[p] < 0 ? nan : y[src[p]]; });
+        return mra_plan_set_obs(pl, yp, R);
+    } catch (const MraError& e) { return fail(pl, e); }
+}
+
+int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_leaf, int64_t N, double* mean, double* var) {
+    if (!pl || !perm || !in_leaf || !mean || !var || N <= 0) return MRA_ERR_INVALID;
+    try {
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        double* st = stage_buffer((size_t)pl->P * 2);
+        const int rc = mra_get_predict(pl, st, st + pl->P);
+        if (rc != MRA_OK) return rc;
+        parallel_rows(N, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { mean[i] = 0.0; var[i] = 0.0; } });
+        const double* mp = st; const double* vp = st + pl->P;
+        // every caller row sits in exactly one padded row, so the scatter has no write conflicts between threads
+        parallel_rows(pl->P, [&](int64_t a, int64_t b) {
+            for (int64_t p = a; p < b; ++p) if (in_leaf[p]) { const int64_t i = perm[p]; if (i >= 0 && i < N) { mean[i] = mp[p]; var[i] = vp[p]; } }
+        });
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
 }

@@ -3,7 +3,6 @@
 // kernels, compiled separately so that the library builds in parallel).
 #pragma once
 #include "mra_kernels.h"
-#include "mra_topology.h"
 #include "../../include/mra_hip.h"
 
 #include <algorithm>
@@ -27,8 +26,11 @@
 // bookkeeping) and the native tree replay through AddressSanitizer / UBSan on a machine without a GPU
 // (`make asan`, tests/test_asan_host.py).  Nothing is computed in this mode.
 static const bool g_dry = []() { const char* e = getenv("MRA_HOST_DRYRUN"); return e && e[0] == '1'; }();
-static inline hipError_t mraMalloc(void** p, size_t n) { if (g_dry) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; } return hipMalloc(p, n); }
-static inline hipError_t mraFree(void* p) { if (g_dry) { free(p); return hipSuccess; } return hipFree(p); }
+// Device allocations go through a small process-wide cache (mra_plan.hip): blocks of a destroyed plan are kept and handed to the
+// next plan that asks for the same size on the same device.  The reference's MLE pattern builds a NEW MRATree per objective call
+// (README.md:96-104): without the cache every call pays hipMalloc + hipFree of ~4 GB (~30 ms at 1024^2) around a 6 ms pass.
+hipError_t mraMalloc(void** p, size_t n);
+hipError_t mraFree(void* p);
 static inline hipError_t mraMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind k) { if (g_dry) { memcpy(d, s_, n); return hipSuccess; } return hipMemcpy(d, s_, n, k); }
 static inline hipError_t mraMemset(void* d, int v, size_t n) { if (g_dry) { memset(d, v, n); return hipSuccess; } return hipMemset(d, v, n); }
 static inline hipError_t mraMemcpy2D(void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h, hipMemcpyKind k) {

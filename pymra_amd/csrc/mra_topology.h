@@ -18,6 +18,8 @@
 #pragma once
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace mra_topo {
@@ -65,6 +67,79 @@ struct MT19937 {
     }
 };
 
+// The raw 32-bit output stream of an MT19937 produced by a helper thread a few blocks ahead of its one consumer (the knot
+// draws of the replay, which are sequential by nature: every shuffle starts where the previous one stopped).  The stream is
+// the generator's, word for word; the state after `consumed` words is rebuilt from the snapshot taken at the start of the
+// block the consumer stopped in.
+struct MTStream {
+    static constexpr int GEN = 624, PER_BLOCK = 128, BLOCK = GEN * PER_BLOCK, NBLOCK = 8;
+    std::vector<uint32_t> ring;                  // NBLOCK blocks of tempered outputs
+    std::vector<uint32_t> snap;                  // key[624] at the start of each ring block
+    std::vector<int> snap_pos;
+    std::atomic<long> produced{0}, released{0};  // blocks written / blocks the consumer is done with
+    std::atomic<bool> stop{false};
+    std::thread th;
+    MT19937 gen;
+    uint32_t key[624], key_init[624];
+    int pos_init;
+    long cur_block = -1;
+    const uint32_t* cur = nullptr;
+    int cur_i = BLOCK;
+    long consumed_blocks = 0;
+    MTStream(const uint32_t* k, int pos) : ring((size_t)NBLOCK * BLOCK), snap((size_t)NBLOCK * 624), snap_pos(NBLOCK), gen{key, pos} {
+        for (int i = 0; i < 624; ++i) key[i] = key_init[i] = k[i];
+        pos_init = pos;
+        th = std::thread([this]() {
+            long b = 0;
+            while (!stop.load(std::memory_order_acquire)) {
+                if (b - released.load(std::memory_order_acquire) >= NBLOCK) { std::this_thread::yield(); continue; }
+                uint32_t* out = ring.data() + (size_t)(b % NBLOCK) * BLOCK;
+                for (int i = 0; i < 624; ++i) snap[(size_t)(b % NBLOCK) * 624 + i] = key[i];
+                snap_pos[b % NBLOCK] = gen.pos;
+                for (int i = 0; i < BLOCK; ++i) out[i] = gen.next32();
+                ++b;
+                produced.store(b, std::memory_order_release);
+            }
+        });
+    }
+    ~MTStream() { stop.store(true, std::memory_order_release); if (th.joinable()) th.join(); }
+    inline uint32_t next32() {
+        if (cur_i == BLOCK) {
+            if (cur_block >= 0) released.store(cur_block + 1, std::memory_order_release);
+            ++cur_block;
+            while (produced.load(std::memory_order_acquire) <= cur_block) std::this_thread::yield();
+            cur = ring.data() + (size_t)(cur_block % NBLOCK) * BLOCK;
+            cur_i = 0;
+        }
+        return cur[cur_i++];
+    }
+    inline uint64_t interval(uint64_t max) {                    // numpy random_interval, as MT19937::interval
+        if (max == 0) return 0;
+        uint64_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        uint64_t v;
+        if (max <= 0xffffffffULL) {
+            while ((v = (next32() & mask)) > max) {}
+        } else {
+            while ((v = ((((uint64_t)next32()) << 32) | next32()) & mask) > max) {}
+        }
+        return v;
+    }
+    // generator state after exactly the words handed out so far
+    void final_state(uint32_t* key_out, int32_t* pos_out) {
+        stop.store(true, std::memory_order_release);
+        if (th.joinable()) th.join();
+        if (cur_block < 0) { for (int i = 0; i < 624; ++i) key_out[i] = key_init[i]; *pos_out = pos_init; return; }
+        uint32_t k2[624];
+        const size_t sb = (size_t)(cur_block % NBLOCK);
+        for (int i = 0; i < 624; ++i) k2[i] = snap[sb * 624 + i];
+        MT19937 g{k2, snap_pos[sb]};
+        for (int i = 0; i < cur_i; ++i) (void)g.next32();
+        for (int i = 0; i < 624; ++i) key_out[i] = k2[i];
+        *pos_out = g.pos;
+    }
+};
+
 struct Result {
     int64_t P = 0;
     int32_t n_nodes = 0, n_levels = 0;
@@ -75,7 +150,7 @@ struct Result {
 
 // returns 0 on success, 1 if the tree does not follow the large-2-D rules (nothing modified)
 inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out) {
-    if (M < 1 || N <= 0 || r <= 0) return 1;
+    if (M < 1 || N <= 0 || r <= 0 || N >= 0x7fffffffLL) return 1;
     // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the
     //      row order so every pass is a sequential sweep
     std::vector<std::vector<int64_t>> orders(M + 1), starts(M + 1);
@@ -84,6 +159,8 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     starts[0] = {0, N};
     std::vector<double> cur(xy, xy + 2 * N), nxt_xy(2 * N);
     std::vector<uint8_t> code(N);
+    const int n_thr = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    int failed = 0;
     for (int m = 0; m < M; ++m) {
         const std::vector<int64_t>& ord = orders[m];
         const std::vector<int64_t>& st = starts[m];
@@ -92,40 +169,83 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         starts[m + 1].assign(4 * nn + 1, 0);
         std::vector<int64_t>& nxt = orders[m + 1];
         std::vector<int64_t>& nst = starts[m + 1];
-        for (int64_t j = 0; j < nn; ++j) {
-            const int64_t s = st[j], e = st[j + 1], n = e - s;
-            if (n <= 100) return 1;
-            double sx = 0.0, sy = 0.0;                       // np.mean(axis=0): sequential accumulation, then / n
-            for (int64_t t = s; t < e; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
-            const double mx = sx / (double)n, my = sy / (double)n;
-            int64_t cnt[4] = {0, 0, 0, 0};
-            for (int64_t t = s; t < e; ++t) {
-                const uint8_t c = (uint8_t)(2 * (cur[2 * t] > mx) + (cur[2 * t + 1] > my));
-                code[t] = c;
-                ++cnt[c];
+        // the nodes of a level are independent (each one's mean is still one sequential accumulation, as np.mean does it):
+        // contiguous node ranges of about equal row counts go to a few threads
+        std::atomic<int> bad{0};
+        auto work = [&](int64_t j0, int64_t j1) {
+            for (int64_t j = j0; j < j1; ++j) {
+                const int64_t s = st[j], e = st[j + 1], n = e - s;
+                if (n <= 100) { bad.store(1); return; }
+                double sx = 0.0, sy = 0.0;                       // np.mean(axis=0): sequential accumulation, then / n
+                for (int64_t t = s; t < e; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
+                const double mx = sx / (double)n, my = sy / (double)n;
+                int64_t cnt[4] = {0, 0, 0, 0};
+                for (int64_t t = s; t < e; ++t) {
+                    const uint8_t c = (uint8_t)(2 * (cur[2 * t] > mx) + (cur[2 * t + 1] > my));
+                    code[t] = c;
+                    ++cnt[c];
+                }
+                if (!cnt[0] || !cnt[1] || !cnt[2] || !cnt[3]) { bad.store(1); return; }
+                int64_t off[4];
+                off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
+                for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
+                for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
+                    const int64_t d = off[code[t]]++;
+                    nxt[d] = ord[t];
+                    nxt_xy[2 * d] = cur[2 * t];
+                    nxt_xy[2 * d + 1] = cur[2 * t + 1];
+                }
             }
-            if (!cnt[0] || !cnt[1] || !cnt[2] || !cnt[3]) return 1;
-            int64_t off[4];
-            off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
-            for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
-            for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
-                const int64_t d = off[code[t]]++;
-                nxt[d] = ord[t];
-                nxt_xy[2 * d] = cur[2 * t];
-                nxt_xy[2 * d + 1] = cur[2 * t + 1];
+        };
+        const int T = (int)std::min<int64_t>(n_thr, nn);
+        if (T <= 1) work(0, nn);
+        else {
+            std::vector<std::thread> pool;
+            int64_t j0 = 0;
+            for (int t = 0; t < T; ++t) {
+                int64_t j1 = j0;
+                const int64_t goal = (N * (t + 1)) / T;
+                while (j1 < nn && (st[j1 + 1] <= goal || j1 == j0)) ++j1;
+                if (t == T - 1) j1 = nn;
+                pool.emplace_back(work, j0, j1);
+                j0 = j1;
             }
+            for (auto& th : pool) th.join();
         }
+        if (bad.load()) { failed = 1; break; }
         nst[4 * nn] = N;
         cur.swap(nxt_xy);
     }
+    if (failed) return 1;
+    // ---- the part of the flat layout that does not depend on the knots, on a helper thread beside the knot draws
+    const int L = M + 1;
+    const int64_t nleaf = (int64_t)1 << (2 * M);
+    std::vector<int64_t> leaf_off(nleaf + 1, 0), pos_of(N, -1);
+    const std::vector<int64_t>& oM = orders[M];
+    std::thread layout([&]() {
+        for (int64_t l = 0; l < nleaf; ++l) {
+            const int64_t c = starts[M][l + 1] - starts[M][l];
+            leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
+        }
+        out.P = leaf_off[nleaf];
+        out.perm.assign(out.P, -1);
+        out.src.assign(out.P, 0);
+        out.in_leaf.assign(out.P, 0);
+        for (int64_t l = 0; l < nleaf; ++l) {
+            const int64_t s = starts[M][l], e = starts[M][l + 1];
+            int64_t p = leaf_off[l];
+            for (int64_t t = s; t < e; ++t, ++p) { out.perm[p] = oM[t]; out.src[p] = oM[t]; out.in_leaf[p] = 1; pos_of[oM[t]] = p; }
+            for (; p < leaf_off[l + 1]; ++p) out.src[p] = oM[s];      // phantom rows copy the leaf's first location
+        }
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{layout};
     // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
-    uint32_t key[624];
-    for (int i = 0; i < 624; ++i) key[i] = mt_key[i];
-    MT19937 rng{key, *mt_pos};
+    MTStream rng(mt_key, *mt_pos);
     std::vector<uint8_t> used(N, 0);
     std::vector<std::vector<int64_t>> knots(M);                // per level: r knots per node, node-major
     for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
-    std::vector<int64_t> cand, perm_idx;
+    std::vector<int64_t> cand;
+    std::vector<int32_t> perm_idx;
     std::vector<std::pair<int, int64_t>> stack;
     stack.push_back({0, 0});
     const int64_t min_cand = std::max<int64_t>(100, std::max<int64_t>(r, 4));
@@ -139,10 +259,23 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         const int64_t nc = (int64_t)cand.size();
         if (nc <= min_cand) return 1;
         perm_idx.resize(nc);
-        for (int64_t i = 0; i < nc; ++i) perm_idx[i] = i;
-        for (int64_t i = nc - 1; i >= 1; --i) {               // RandomState.shuffle: _shuffle_raw
-            const int64_t k = (int64_t)rng.interval((uint64_t)i);
-            std::swap(perm_idx[i], perm_idx[k]);
+        for (int64_t i = 0; i < nc; ++i) perm_idx[i] = (int32_t)i;
+        // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[interval(i)].  The draws do not depend on the
+        // array, so they are made a batch ahead and their targets prefetched: on the upper levels (10^5 - 10^6 candidates) the
+        // array does not fit the cache and every swap was a miss (12 ns each, most of the replay's 90 ms at 1024^2)
+        {
+            constexpr int BATCH = 32;
+            int64_t kbuf[BATCH];
+            int64_t i = nc - 1;
+            while (i >= 1) {
+                const int nb = (int)std::min<int64_t>(BATCH, i);
+                for (int b = 0; b < nb; ++b) {
+                    kbuf[b] = (int64_t)rng.interval((uint64_t)(i - b));
+                    __builtin_prefetch(&perm_idx[kbuf[b]], 1, 1);
+                }
+                for (int b = 0; b < nb; ++b) std::swap(perm_idx[i - b], perm_idx[kbuf[b]]);
+                i -= nb;
+            }
         }
         int64_t* kn = knots[m].data() + j * r;
         for (int i = 0; i < r; ++i) kn[i] = cand[perm_idx[i]];
@@ -150,31 +283,13 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         for (int i = 0; i < r; ++i) used[kn[i]] = 1;
         if (m + 1 < M) for (int c = 3; c >= 0; --c) stack.push_back({m + 1, 4 * j + c});
     }
-    // ---- flat layout
-    const int L = M + 1;
+    // ---- flat layout: node arrays and knot rows (needs the knots and the helper thread's row positions)
+    layout.join();
     out.n_levels = L;
     out.level_ptr.assign(L + 1, 0);
     for (int m = 0; m < L; ++m) out.level_ptr[m + 1] = out.level_ptr[m] + ((int64_t)1 << (2 * m));
     const int64_t nn = out.level_ptr[L];
     out.n_nodes = (int32_t)nn;
-    const int64_t nleaf = (int64_t)1 << (2 * M);
-    std::vector<int64_t> leaf_off(nleaf + 1, 0);
-    for (int64_t l = 0; l < nleaf; ++l) {
-        const int64_t c = starts[M][l + 1] - starts[M][l];
-        leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
-    }
-    out.P = leaf_off[nleaf];
-    out.perm.assign(out.P, -1);
-    out.src.assign(out.P, 0);
-    out.in_leaf.assign(out.P, 0);
-    std::vector<int64_t> pos_of(N, -1);
-    const std::vector<int64_t>& oM = orders[M];
-    for (int64_t l = 0; l < nleaf; ++l) {
-        const int64_t s = starts[M][l], e = starts[M][l + 1];
-        int64_t p = leaf_off[l];
-        for (int64_t t = s; t < e; ++t, ++p) { out.perm[p] = oM[t]; out.src[p] = oM[t]; out.in_leaf[p] = 1; pos_of[oM[t]] = p; }
-        for (; p < leaf_off[l + 1]; ++p) out.src[p] = oM[s];      // phantom rows copy the leaf's first location
-    }
     out.level.assign(nn, 0); out.row0.assign(nn, 0); out.row1.assign(nn, 0); out.leaf.assign(nn, 0);
     out.parent.assign(nn, -1); out.child_ptr.assign(nn + 1, 0);
     out.child_list.clear();
@@ -220,8 +335,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             }
         }
     }
-    for (int i = 0; i < 624; ++i) mt_key[i] = key[i];
-    *mt_pos = rng.pos;
+    rng.final_state(mt_key, mt_pos);
     return 0;
 }
 

@@ -33,8 +33,8 @@ ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4
 
 # every symbol include/mra_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
-    "mra_device_count", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
-    "mra_plan_set_kernel", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
+    "mra_device_count", "mra_release_cached_memory", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
+    "mra_plan_set_kernel", "mra_plan_set_locs_rows", "mra_plan_set_obs_rows", "mra_get_predict_rows", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
     "mra_get_buffer", "mra_get_node_block", "mra_get_timers", "mra_plan_set_option", "mra_plan_get_option", "mra_plan_prepare", "mra_kernel_family_count",
     "mra_get_kernel_stats", "mra_get_kernel_work", "mra_device_synchronize", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
@@ -72,10 +72,14 @@ def load_library():
     vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
     sig = {
         "mra_device_count": (C.c_int, []),
+        "mra_release_cached_memory": (C.c_int, []),
         "mra_plan_create": (C.c_int, [C.POINTER(vp), C.POINTER(MraTopologyStruct), C.c_int]),
         "mra_plan_destroy": (C.c_int, [vp]),
         "mra_plan_set_locs": (C.c_int, [vp, vp]),
         "mra_plan_set_obs": (C.c_int, [vp, vp, dbl]),
+        "mra_plan_set_locs_rows": (C.c_int, [vp, vp, vp]),
+        "mra_plan_set_obs_rows": (C.c_int, [vp, vp, vp, vp, dbl]),
+        "mra_get_predict_rows": (C.c_int, [vp, vp, vp, i64, vp, vp]),
         "mra_plan_set_kernel": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "mra_plan_set_cov_block": (C.c_int, [vp, i32, vp, i64, i64, vp]),
         "mra_eval_kernel": (C.c_int, [C.c_int, vp, C.c_int, vp, i64, vp]),
@@ -167,23 +171,29 @@ class HipPlan:
             pass
 
     # -- inputs --------------------------------------------------------------------------------
+    def _row_maps(self):
+        if getattr(self, "_maps", None) is None:
+            t = self.topo
+            self._maps = (np.ascontiguousarray(t.src, dtype=np.int64), np.ascontiguousarray(t.perm, dtype=np.int64),
+                          np.ascontiguousarray(t.in_leaf, dtype=np.uint8))
+        return self._maps
+
     def set_locs(self, locs):
-        """locs: the caller's N x d array; permuted/padded here."""
-        X = np.asarray(locs, dtype=np.float64)
+        """locs: the caller's N x d array; permuted/padded inside the library."""
+        X = np.ascontiguousarray(locs, dtype=np.float64)
         if X.ndim == 1:
             X = X.reshape(-1, 1)
-        src = self.topo.src
-        Xp = np.empty((len(src), X.shape[1]))
-        for c in range(X.shape[1]):                       # column-wise gathers are several times faster than X[src]
-            Xp[:, c] = np.ascontiguousarray(X[:, c])[src]
-        self._check(self.lib.mra_plan_set_locs(self._h, _ptr(Xp)))
+        if X.shape != (self.topo.N, self.d):
+            raise ValueError("locs must be N x d")
+        src, _, _ = self._row_maps()
+        self._check(self.lib.mra_plan_set_locs_rows(self._h, _ptr(X), _ptr(src)))
 
     def set_obs(self, obs, R):
-        y = np.asarray(obs, dtype=np.float64).reshape(-1)
-        yp = y[self.topo.src].copy()
-        yp[self.topo.perm < 0] = np.nan
-        yp = np.ascontiguousarray(yp)
-        self._check(self.lib.mra_plan_set_obs(self._h, _ptr(yp), float(R)))
+        y = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(-1))
+        if len(y) != self.topo.N:
+            raise ValueError("obs must have N entries")
+        src, perm, _ = self._row_maps()
+        self._check(self.lib.mra_plan_set_obs_rows(self._h, _ptr(y), _ptr(src), _ptr(perm), float(R)))
 
     def set_kernel(self, kind, l, sig=1.0, scale=1.0, circular=False):
         par = np.array([l, sig, scale, 1.0 if circular else 0.0], dtype=np.float64)
@@ -265,15 +275,11 @@ class HipPlan:
     def predict(self):
         """(mean[N], var[N]) in the caller's row order; rows outside every leaf report 0 (see
         topology: rows that a partition drops, pyMRA/MRANode.py:222-228, 492-495)."""
-        mp = np.empty(self.P)
-        vp = np.empty(self.P)
-        self._check(self.lib.mra_get_predict(self._h, _ptr(mp), _ptr(vp)))
         t = self.topo
-        mean = np.zeros(t.N)
-        var = np.zeros(t.N)
-        good = t.in_leaf
-        mean[t.perm[good]] = mp[good]
-        var[t.perm[good]] = vp[good]
+        _, perm, in_leaf = self._row_maps()
+        mean = np.empty(t.N)
+        var = np.empty(t.N)
+        self._check(self.lib.mra_get_predict_rows(self._h, _ptr(perm), _ptr(in_leaf), int(t.N), _ptr(mean), _ptr(var)))
         return mean, var
 
     def buffer(self, what):
@@ -364,3 +370,8 @@ def device_synchronize(device: int = 0) -> None:
     rc = load_library().mra_device_synchronize(int(device))
     if rc != 0:
         raise MraError(rc, "hipDeviceSynchronize failed")
+
+
+def release_cached_memory() -> None:
+    """Return the device blocks the library keeps from destroyed plans (reused by later plans of the same sizes) to the driver."""
+    load_library().mra_release_cached_memory()

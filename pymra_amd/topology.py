@@ -30,6 +30,7 @@ from dataclasses import dataclass, field
 from typing import List, Optional
 
 import numpy as np
+from collections.abc import Sequence
 
 logger = logging.getLogger("pyMRA.MRATree")
 
@@ -252,6 +253,35 @@ class Topology:
         return np.diff(self.level_ptr)
 
 
+class _LazyIdents(Sequence):
+    """Node names of a native quadtree replay ("r", "r1", "r13", ...: the reference's Node.ID, pyMRA/MRANode.py:26-28), built
+    on first use: diagnostics and tests read them, the inference path never does, and the Python loop over all nodes costs
+    milliseconds at 1024^2."""
+
+    def __init__(self, parent, level, level_ptr):
+        self._parent, self._level, self._lp, self._ids = parent, level, level_ptr, None
+
+    def _build(self):
+        if self._ids is None:
+            n = len(self._parent)
+            ids = [""] * n
+            if n:
+                ids[0] = "r"
+            for i in range(1, n):
+                ids[i] = ids[self._parent[i]] + str(int((i - self._lp[self._level[i]]) % 4) + 1)
+            self._ids = ids
+        return self._ids
+
+    def __len__(self):
+        return len(self._parent)
+
+    def __getitem__(self, i):
+        return self._build()[i]
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 def _replay_native(coords: np.ndarray, r: int, M: int, J: int) -> Optional[Topology]:
     """Large 2-D trees: the replay runs in libmra_hip.so (csrc/mra_topology.h; host code, no GPU needed),
     driven by and returning NumPy's global MT19937 state.  None when the library is not built or the tree
@@ -290,11 +320,7 @@ def _replay_native(coords: np.ndarray, r: int, M: int, J: int) -> Optional[Topol
     finally:
         lib.mra_tree_free(handle)
     np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
-    idents = [""] * n_nodes
-    idents[0] = "r"
-    lp = a["level_ptr"]
-    for i in range(1, n_nodes):
-        idents[i] = idents[a["parent"][i]] + str(int((i - lp[a["node_level"][i]]) % 4) + 1)
+    idents = _LazyIdents(a["parent"], a["node_level"], a["level_ptr"])
     return Topology(N=len(xy), d=2, M=M, J=J, r=r, P=P, perm=a["perm"], src=a["src"], in_leaf=a["in_leaf"].astype(bool),
                     n_nodes=n_nodes, n_levels=n_levels, level_ptr=a["level_ptr"], node_level=a["node_level"],
                     node_row0=a["row0"], node_row1=a["row1"], node_leaf=a["leaf"].astype(bool), node_parent=a["parent"],

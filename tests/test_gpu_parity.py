@@ -541,3 +541,33 @@ def test_random_geometries(hip, seed):
     d, u = pl.likelihood()
     assert abs(d + u - lik) <= 1e-11 * max(1.0, abs(lik))
     pl.close()
+
+
+def test_leaves_without_any_observation(hip):
+    """A leaf with no observed row has a zero-sized panel (nop = 0).  The fused row solve + update (MRA_OPT_LEAF_SOLVE = 1, the
+    default of 8-way sharded runs) and the update folded into the predictive cascade (MRA_OPT_PRED_UPDATE = 1) must skip it
+    without reading past the panel allocation - the LAST leaf is one of the empty ones - and agree with the level-by-level
+    kernels and with the CPU oracle."""
+    from oracle.mra_levelwise import run_levelwise
+    cs = dict(K.load_case("c2"))
+    t = cs["topo"]
+    y = np.array(cs["y_obs"], dtype=np.float64).reshape(-1, 1)
+    leaves = [i for i in range(t.n_nodes) if t.node_leaf[i]]
+    for i in (leaves[0], leaves[37], leaves[-1]):
+        rows = t.perm[int(t.node_row0[i]):int(t.node_row1[i])]
+        y[rows[rows >= 0]] = np.nan
+    cs["y_obs"] = y
+    ref = run_levelwise(t, cs["locs"], cs["spec"], y, cs["c"]["R"])
+    pl, lik, mean, var = run_hip(hip, cs)
+    assert abs(lik - ref["lik"]) <= 1e-11 * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-10 and K.rel(np.sqrt(var), ref["sd"]) < 1e-9
+    for opts in ((7, 1), (8, 1, 7, 0), (8, 0, 7, 0), (2, 0)):
+        pl.set_option(2, 1); pl.set_option(7, 2); pl.set_option(8, 1)
+        for o, v in zip(opts[::2], opts[1::2]):
+            pl.set_option(o, v)
+        pl.run(True, True)
+        d, u = pl.likelihood()
+        m2, v2 = pl.predict()
+        assert abs(d + u - lik) <= 1e-12 * abs(lik), opts
+        assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10, opts
+    pl.close()
