@@ -180,6 +180,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_LEAF_SOLVE     7   /* row solve Tt = V Lc^-T and leaf update in one launch (k_leaf_solve_update, Tt stays in registers):
                                       2 (default) when a CU sees at most two leaves (8-way sharded runs), 1 always, 0 never */
 #define MRA_OPT_PRED_UPDATE    8   /* 1 (default): the leaf update is applied inside the predictive cascade (W is not rewritten); 0: separate product */
+#define MRA_OPT_LEAF_FACTOR    9   /* 1 (default): when a CU sees at most two leaves, their Cholesky runs in LDS on one workgroup per leaf with the Ut
+                                      row solve in the same launch (k_leaf_factor); 0: one wave per matrix (k_chol_wave) + separate row solve */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 /* current value of an option (so that a caller can change one temporarily and put it back) */
@@ -209,6 +211,12 @@ int mra_plan_info(mra_plan *plan, int64_t *out, int capacity);
 typedef struct mra_tree mra_tree;
 int mra_tree_replay_2d(const double *locs, int64_t N, int32_t r, int32_t M, uint32_t *mt_key, int32_t *mt_pos,
                        mra_tree **out);
+/* The same replay writing the four long arrays (perm, src, in_leaf: P <= cap_rows entries; knot_rows: N entries) straight into
+ * caller buffers of capacity cap_rows >= N + 15 * 4^M (every leaf is padded to a multiple of 16 rows); mra_tree_export then
+ * skips them (pass NULL).  Saves ~25 MB of copies and unmapping per tree: an end-to-end MRATree(...) call is mostly this. */
+int mra_tree_replay_2d_into(const double *locs, int64_t N, int32_t r, int32_t M, uint32_t *mt_key, int32_t *mt_pos,
+                            int64_t cap_rows, int64_t *perm, int64_t *src, uint8_t *in_leaf, int64_t *knot_rows,
+                            mra_tree **out);
 /* out5 = {P, n_nodes, n_levels, len(child_list), len(knot_rows)} */
 int mra_tree_sizes(mra_tree *t, int64_t *out5);
 /* copies the arrays of `mra_topology` (+ perm, src, in_leaf, node_level, pre-order) into caller buffers */

@@ -45,7 +45,7 @@ class RootView:
     def __init__(self, d, u, mean, var, N, topo, locs=None, kernel=None):
         self.d = np.matrix([[d]])
         self.u = np.matrix([[u]])
-        self.mean = np.matrix(mean).reshape(N, 1) if mean is not None else None
+        self.mean = np.asmatrix(mean).reshape(N, 1) if mean is not None else None      # a view: no 8 MB copy
         self.var = var
         self.N = N
         self.res = 0

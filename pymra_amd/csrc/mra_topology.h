@@ -19,6 +19,11 @@
 #include <stdint.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -125,6 +130,39 @@ struct MTStream {
         }
         return v;
     }
+    // Steps i = i_hi .. i_lo of the shuffle in their store-only form p[interval(i)] = p[i] (see replay_quadtree), straight off
+    // the ring: random_interval(i) masks a 32-bit word with the smallest 2^k - 1 >= i and rejects values > i.  Written without a
+    // data-dependent branch - a rejected word stores p[i] onto itself and does not advance i - because the rejection is a coin
+    // flip right below every power of two and mispredicts cost more than the arithmetic.  On return i = i_lo - 1.
+    inline void shuffle_stores(int32_t* pp, int64_t& i, int64_t i_lo) {
+        while (i >= i_lo) {
+            uint64_t mask = (uint64_t)i;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+            const int64_t lo = std::max<int64_t>(i_lo, (int64_t)(mask >> 1) + 1);     // the mask is the same for i in [lo, i]
+            const uint32_t m32 = (uint32_t)mask;
+            while (i >= lo) {
+                if (cur_i == BLOCK) {
+                    if (cur_block >= 0) released.store(cur_block + 1, std::memory_order_release);
+                    ++cur_block;
+                    while (produced.load(std::memory_order_acquire) <= cur_block) std::this_thread::yield();
+                    cur = ring.data() + (size_t)(cur_block % NBLOCK) * BLOCK;
+                    cur_i = 0;
+                }
+                const uint32_t* w = cur + cur_i;
+                const int nw = BLOCK - cur_i;
+                int k = 0;
+                int64_t ii = i;
+                for (; k < nw && ii >= lo; ++k) {
+                    const int64_t v = (int64_t)(w[k] & m32);
+                    const bool ok = v <= ii;
+                    pp[ok ? v : ii] = pp[ii];
+                    ii -= ok;
+                }
+                cur_i += k;
+                i = ii;
+            }
+        }
+    }
     // generator state after exactly the words handed out so far
     void final_state(uint32_t* key_out, int32_t* pos_out) {
         stop.store(true, std::memory_order_release);
@@ -141,6 +179,10 @@ struct MTStream {
 };
 
 struct Result {
+    // optional caller-owned destinations of the four long arrays (capacity: N + 15 * 4^M rows, N knot rows): when set the replay
+    // writes them in place and the vectors of the same name stay empty (no 25 MB of copies and unmapping per tree)
+    int64_t* ext_perm = nullptr; int64_t* ext_src = nullptr; uint8_t* ext_in_leaf = nullptr; int64_t* ext_knot_rows = nullptr;
+    int64_t n_knot_rows = 0;
     int64_t P = 0;
     int32_t n_nodes = 0, n_levels = 0;
     std::vector<int64_t> perm, src, level_ptr, row0, row1, knot_ptr, knot_rows;
@@ -151,23 +193,50 @@ struct Result {
 // returns 0 on success, 1 if the tree does not follow the large-2-D rules (nothing modified)
 inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out) {
     if (M < 1 || N <= 0 || r <= 0 || N >= 0x7fffffffLL) return 1;
+    const bool trace = getenv("MRA_TRACE_REPLAY") != nullptr;         // phase times on stderr (tools/e2e_breakdown.py)
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_cand = 0, t_shuf = 0;
     // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the
     //      row order so every pass is a sequential sweep
-    std::vector<std::vector<int64_t>> orders(M + 1), starts(M + 1);
+    // Work arrays live in a process-wide scratch area that only grows: a fresh 100 MB of vectors per call costs more in page
+    // faults and unmapping (10 + 10 ms at 1024^2) than a partition level does, and MLE loops replay the same tree size again
+    // and again (README.md:96-104 builds a new MRATree per objective call).  One replay at a time.
+    struct Scratch {
+        std::vector<std::vector<int32_t>> orders, inv;
+        std::vector<std::vector<int64_t>> starts, knots;
+        std::vector<double> cur, nxt_xy;
+        std::vector<uint8_t> code, used;
+        std::vector<int32_t> leaf_of, perm_idx;
+        std::vector<int64_t> leaf_off, pos_of;
+    };
+    static Scratch ws;
+    static std::mutex ws_mutex;
+    std::lock_guard<std::mutex> ws_lock(ws_mutex);
+    auto& orders = ws.orders; auto& starts = ws.starts;
+    if ((int)orders.size() < M + 1) orders.resize(M + 1);
+    if ((int)starts.size() < M + 1) starts.resize(M + 1);
     orders[0].resize(N);
-    for (int64_t i = 0; i < N; ++i) orders[0][i] = i;
+    for (int64_t i = 0; i < N; ++i) orders[0][i] = (int32_t)i;
     starts[0] = {0, N};
-    std::vector<double> cur(xy, xy + 2 * N), nxt_xy(2 * N);
-    std::vector<uint8_t> code(N);
+    auto& cur = ws.cur; auto& nxt_xy = ws.nxt_xy; auto& code = ws.code;
+    cur.resize(2 * N); nxt_xy.resize(2 * N); code.resize(N);
+    memcpy(cur.data(), xy, (size_t)2 * N * sizeof(double));
+    // inv[m][x] = position of caller row x in orders[m] (levels 1 .. M-1; level 0 is the identity), leaf_of[x] = its leaf:
+    // written by the partition threads, they let the knot phase find "the k-th not-yet-used row of a node" without scanning the node
+    auto& inv = ws.inv; auto& leaf_of = ws.leaf_of;
+    if ((int)inv.size() < M) inv.resize(M);
+    for (int m = 1; m < M; ++m) inv[m].resize(N);
+    leaf_of.resize(N);
     const int n_thr = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
     int failed = 0;
     for (int m = 0; m < M; ++m) {
-        const std::vector<int64_t>& ord = orders[m];
+        const std::vector<int32_t>& ord = orders[m];
         const std::vector<int64_t>& st = starts[m];
         const int64_t nn = (int64_t)st.size() - 1;
         orders[m + 1].resize(N);
         starts[m + 1].assign(4 * nn + 1, 0);
-        std::vector<int64_t>& nxt = orders[m + 1];
+        std::vector<int32_t>& nxt = orders[m + 1];
         std::vector<int64_t>& nst = starts[m + 1];
         // the nodes of a level are independent (each one's mean is still one sequential accumulation, as np.mean does it):
         // contiguous node ranges of about equal row counts go to a few threads
@@ -189,11 +258,15 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                 int64_t off[4];
                 off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
                 for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
+                int32_t* const inv_next = (m + 1 < M) ? inv[m + 1].data() : nullptr;
                 for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
                     const int64_t d = off[code[t]]++;
-                    nxt[d] = ord[t];
+                    const int32_t x = ord[t];
+                    nxt[d] = x;
                     nxt_xy[2 * d] = cur[2 * t];
                     nxt_xy[2 * d + 1] = cur[2 * t + 1];
+                    if (inv_next) inv_next[x] = (int32_t)d;
+                    else leaf_of[x] = (int32_t)(4 * j + code[t]);
                 }
             }
         };
@@ -217,35 +290,40 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         cur.swap(nxt_xy);
     }
     if (failed) return 1;
+    const double t_part = now();
     // ---- the part of the flat layout that does not depend on the knots, on a helper thread beside the knot draws
     const int L = M + 1;
     const int64_t nleaf = (int64_t)1 << (2 * M);
-    std::vector<int64_t> leaf_off(nleaf + 1, 0), pos_of(N, -1);
-    const std::vector<int64_t>& oM = orders[M];
+    auto& leaf_off = ws.leaf_off; auto& pos_of = ws.pos_of;
+    leaf_off.assign(nleaf + 1, 0);
+    pos_of.resize(N);                                    // every caller row sits in exactly one leaf: all entries are written below
+    const std::vector<int32_t>& oM = orders[M];
     std::thread layout([&]() {
         for (int64_t l = 0; l < nleaf; ++l) {
             const int64_t c = starts[M][l + 1] - starts[M][l];
             leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
         }
         out.P = leaf_off[nleaf];
-        out.perm.assign(out.P, -1);
-        out.src.assign(out.P, 0);
-        out.in_leaf.assign(out.P, 0);
+        if (!out.ext_perm) { out.perm.resize(out.P); out.src.resize(out.P); out.in_leaf.resize(out.P); }
+        int64_t* const perm_o = out.ext_perm ? out.ext_perm : out.perm.data();
+        int64_t* const src_o = out.ext_perm ? out.ext_src : out.src.data();
+        uint8_t* const inl_o = out.ext_perm ? out.ext_in_leaf : out.in_leaf.data();
         for (int64_t l = 0; l < nleaf; ++l) {
             const int64_t s = starts[M][l], e = starts[M][l + 1];
             int64_t p = leaf_off[l];
-            for (int64_t t = s; t < e; ++t, ++p) { out.perm[p] = oM[t]; out.src[p] = oM[t]; out.in_leaf[p] = 1; pos_of[oM[t]] = p; }
-            for (; p < leaf_off[l + 1]; ++p) out.src[p] = oM[s];      // phantom rows copy the leaf's first location
+            for (int64_t t = s; t < e; ++t, ++p) { perm_o[p] = oM[t]; src_o[p] = oM[t]; inl_o[p] = 1; pos_of[oM[t]] = p; }
+            for (; p < leaf_off[l + 1]; ++p) { perm_o[p] = -1; src_o[p] = oM[s]; inl_o[p] = 0; }      // phantom rows copy the leaf's first location
         }
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{layout};
     // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
     MTStream rng(mt_key, *mt_pos);
-    std::vector<uint8_t> used(N, 0);
-    std::vector<std::vector<int64_t>> knots(M);                // per level: r knots per node, node-major
+    auto& used = ws.used; auto& knots = ws.knots; auto& perm_idx = ws.perm_idx;
+    used.assign(N, 0);
+    if ((int)knots.size() < M) knots.resize(M);                // per level: r knots per node, node-major
     for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
-    std::vector<int64_t> cand;
-    std::vector<int32_t> perm_idx;
+    std::vector<int32_t> upos;
+    std::vector<int64_t> picks(r);
     std::vector<std::pair<int, int64_t>> stack;
     stack.push_back({0, 0});
     const int64_t min_cand = std::max<int64_t>(100, std::max<int64_t>(r, 4));
@@ -254,37 +332,54 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         const int64_t j = stack.back().second;
         stack.pop_back();
         const int64_t s = starts[m][j], e = starts[m][j + 1];
-        cand.clear();
-        for (int64_t t = s; t < e; ++t) if (!used[orders[m][t]]) cand.push_back(orders[m][t]);
-        const int64_t nc = (int64_t)cand.size();
+        const double tc0 = trace ? now() : 0.0;
+        // positions (inside this node's row order) of the rows its ancestors took as knots: at most r per ancestor
+        upos.clear();
+        for (int k = 0; k < m; ++k) {
+            const int64_t* ak = knots[k].data() + (j >> (2 * (m - k))) * r;
+            for (int i = 0; i < r; ++i) {
+                const int64_t x = ak[i];
+                if (((int64_t)leaf_of[x] >> (2 * (M - m))) == j) upos.push_back((int32_t)(inv[m][x] - s));     // m >= 1 here
+            }
+        }
+        std::sort(upos.begin(), upos.end());
+        const int64_t nc = (e - s) - (int64_t)upos.size();        // candidates = rows of the node not used by an ancestor
         if (nc <= min_cand) return 1;
         perm_idx.resize(nc);
         for (int64_t i = 0; i < nc; ++i) perm_idx[i] = (int32_t)i;
-        // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[interval(i)].  The draws do not depend on the
-        // array, so they are made a batch ahead and their targets prefetched: on the upper levels (10^5 - 10^6 candidates) the
-        // array does not fit the cache and every swap was a miss (12 ns each, most of the replay's 90 ms at 1024^2)
+        const double tc1 = trace ? now() : 0.0;
+        // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[interval(i)], and the knots are p[0 .. r-1].
+        // Position i is never touched again after step i (later steps pick targets <= their own i), so for i >= r only the
+        // store p[k] = p[i] matters: one sequential read and one random STORE per step - no random load, nothing to wait for
+        // (with the full swap every step was a cache miss on the upper levels, whose arrays of 10^5 - 10^6 entries exceed the cache)
         {
-            constexpr int BATCH = 32;
-            int64_t kbuf[BATCH];
             int64_t i = nc - 1;
-            while (i >= 1) {
-                const int nb = (int)std::min<int64_t>(BATCH, i);
-                for (int b = 0; b < nb; ++b) {
-                    kbuf[b] = (int64_t)rng.interval((uint64_t)(i - b));
-                    __builtin_prefetch(&perm_idx[kbuf[b]], 1, 1);
-                }
-                for (int b = 0; b < nb; ++b) std::swap(perm_idx[i - b], perm_idx[kbuf[b]]);
-                i -= nb;
+            int32_t* const pp = perm_idx.data();
+            rng.shuffle_stores(pp, i, (int64_t)std::max<int32_t>(r, 1));        // steps i = nc-1 .. r
+            for (; i >= 1; --i) std::swap(pp[i], pp[rng.interval((uint64_t)i)]);
+        }
+        // the r picks are indices into the candidate list (ascending row order): map the k-th candidate to its row by stepping
+        // over the ancestors' knots; the reference re-sorts the knots into location order (MRANode.py:203-204) = ascending pick
+        for (int i = 0; i < r; ++i) picks[i] = perm_idx[i];
+        std::sort(picks.begin(), picks.end());
+        if (trace) { const double tc2 = now(); t_cand += tc1 - tc0; t_shuf += tc2 - tc1; }
+        int64_t* kn = knots[m].data() + j * r;
+        {
+            size_t u = 0;
+            const int32_t* om = orders[m].data() + s;
+            for (int i = 0; i < r; ++i) {
+                int64_t pos = picks[i] + (int64_t)u;
+                while (u < upos.size() && upos[u] <= pos) { ++u; ++pos; }
+                kn[i] = om[pos];
             }
         }
-        int64_t* kn = knots[m].data() + j * r;
-        for (int i = 0; i < r; ++i) kn[i] = cand[perm_idx[i]];
-        std::sort(kn, kn + r);
         for (int i = 0; i < r; ++i) used[kn[i]] = 1;
         if (m + 1 < M) for (int c = 3; c >= 0; --c) stack.push_back({m + 1, 4 * j + c});
     }
     // ---- flat layout: node arrays and knot rows (needs the knots and the helper thread's row positions)
+    const double t_knots = now();
     layout.join();
+    const double t_join = now();
     out.n_levels = L;
     out.level_ptr.assign(L + 1, 0);
     for (int m = 0; m < L; ++m) out.level_ptr[m + 1] = out.level_ptr[m] + ((int64_t)1 << (2 * m));
@@ -295,7 +390,9 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     out.child_list.clear();
     out.knot_ptr.assign(nn + 1, 0);
     out.knot_rows.clear();
-    out.knot_rows.reserve(N);
+    if (!out.ext_knot_rows) out.knot_rows.resize(N);          // every caller row is the knot of exactly one node (leaves take what is left)
+    int64_t* const kr_o = out.ext_knot_rows ? out.ext_knot_rows : out.knot_rows.data();
+    int64_t nkr = 0;
     for (int m = 0; m < L; ++m) {
         const int64_t span = (int64_t)1 << (2 * (M - m));
         for (int64_t j = 0; j < ((int64_t)1 << (2 * m)); ++j) {
@@ -308,15 +405,17 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             if (m < M) {
                 for (int c = 0; c < 4; ++c) out.child_list.push_back((int32_t)(out.level_ptr[m + 1] + 4 * j + c));
                 const int64_t* kn = knots[m].data() + j * r;
-                for (int t = 0; t < r; ++t) out.knot_rows.push_back(pos_of[kn[t]]);
+                for (int t = 0; t < r; ++t) kr_o[nkr++] = pos_of[kn[t]];
             } else {
                 const int64_t s = starts[M][j], e = starts[M][j + 1];
-                for (int64_t t = s; t < e; ++t) if (!used[oM[t]]) out.knot_rows.push_back(pos_of[oM[t]]);
+                for (int64_t t = s; t < e; ++t) if (!used[oM[t]]) kr_o[nkr++] = pos_of[oM[t]];
             }
             out.child_ptr[i + 1] = (int32_t)out.child_list.size();
-            out.knot_ptr[i + 1] = (int64_t)out.knot_rows.size();
+            out.knot_ptr[i + 1] = nkr;
         }
     }
+    out.n_knot_rows = nkr;
+    if (!out.ext_knot_rows) out.knot_rows.resize(nkr);
     out.cw.assign(L, 0);
     for (int m = 0; m < M; ++m) out.cw[m] = (r + 15) / 16 * 16;
     out.preorder.clear();
@@ -335,7 +434,10 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             }
         }
     }
+    const double t_nodes = now();
     rng.final_state(mt_key, mt_pos);
+    if (trace) fprintf(stderr, "replay_quadtree N=%lld: partition %.1f ms, knots %.1f ms (candidates %.1f, shuffles %.1f), layout join %.1f ms, node arrays %.1f ms, rng state %.1f ms\n",
+                       (long long)N, t_part - t_begin, t_knots - t_part, t_cand, t_shuf, t_join - t_knots, t_nodes - t_join, now() - t_nodes);
     return 0;
 }
 

@@ -26,6 +26,7 @@ MRA_OPT_KNOT_CHAIN = 5
 MRA_OPT_LEAF_GEMM = 6
 MRA_OPT_LEAF_SOLVE = 7
 MRA_OPT_PRED_UPDATE = 8
+MRA_OPT_LEAF_FACTOR = 9
 MRA_BLOCK_W_ROWS, MRA_BLOCK_LPRIOR, MRA_BLOCK_FRONT, MRA_BLOCK_LEAF = 0, 1, 2, 3
 
 ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4: "MRA_ERR_STATE",
@@ -39,7 +40,7 @@ EXPORTS = [
     "mra_get_kernel_stats", "mra_get_kernel_work", "mra_device_synchronize", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
     "mra_run_resume", "mra_last_error", "mra_version",
-    "mra_tree_replay_2d", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
+    "mra_tree_replay_2d", "mra_tree_replay_2d_into", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
 ]
 
 
@@ -105,6 +106,7 @@ def load_library():
         "mra_reduce_export": (C.c_int, [vp, vp]),
         "mra_reduce_import": (C.c_int, [vp, vp]),
         "mra_tree_replay_2d": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(vp)]),
+        "mra_tree_replay_2d_into": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), i64, vp, vp, vp, vp, C.POINTER(vp)]),
         "mra_tree_sizes": (C.c_int, [vp, vp]),
         "mra_tree_export": (C.c_int, [vp] + [vp] * 15),
         "mra_tree_free": (C.c_int, [vp]),

@@ -20,6 +20,7 @@ def step():
     else: pl.run(True, True, split=True); pl.resume()
 VALS = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 0]
 res = {v: [] for v in VALS}
+lik = {}
 for rnd in range(6):
     for v in VALS:
         pl.set_option(opt, v)
@@ -27,5 +28,6 @@ for rnd in range(6):
         t0 = time.perf_counter()
         for _ in range(20): step()
         res[v].append((time.perf_counter() - t0) / 20 * 1e3)
+        lik[v] = sum(pl.likelihood())
 for v in VALS:
-    print("option %d = %d: median %.3f ms  min %.3f ms  (%s)" % (opt, v, float(np.median(res[v])), min(res[v]), " ".join("%.3f" % x for x in res[v])))
+    print("option %d = %d: median %.3f ms  min %.3f ms  (%s)" % (opt, v, float(np.median(res[v])), min(res[v]), " ".join("%.3f" % x for x in res[v])), " d+u = %.10f" % lik[v])
