@@ -1390,147 +1390,6 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
 }
 
 // ------------------------------------------------------------------------------------------------
-//  Leaf factorisation for runs with FEW leaves per CU (a rank of an 8-way sharded tree: two leaves per CU): the whole
-//  Cholesky of C = v_m(o,o) + R I (MRANode.py:444, 456-458 in observation space) in LDS on one 8-wave workgroup per leaf,
-//  and the row solve of the leaf's Ut block behind it in the same launch.  k_chol_wave keeps the matrix in global memory and
-//  walks it with one wave: ~95 us per matrix of dependent L2 round trips however few matrices there are - fine when sixteen of
-//  them overlap on a CU, the critical path of the pass when there are two.  Here the lower tiles live in LDS (k_front's
-//  layout and its left-looking panel loop with every column a panel column): ~5 us per 16-column step.
-//  Writes Lc (lower tiles) and the inverted diagonal blocks back for the kernels that follow (k_leaf_solve_update stages them
-//  again), Ut solved in place, log det C into dnode.
-// ------------------------------------------------------------------------------------------------
-struct LeafFactorProb {
-    double* C;            // nt*16 square, row-major, ld (lower part used; factor written in place)
-    double* invd;         // nt inverted diagonal blocks (256 doubles each)
-    double* Ut;           // nat*16 rows x nt*16, row-major, ld: solved in place (X = Ut Lc^-T)
-    long ld;
-    int nt, nat, node;
-};
-
-template <int NTMAX>
-__global__ __launch_bounds__(512, 1) void k_leaf_factor(const LeafFactorProb* __restrict__ probs, double* __restrict__ dnode, int* __restrict__ err) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const LeafFactorProb* __restrict__ pp = probs + blockIdx.x;
-    const int nt = pp->nt, nat = pp->nat;
-    const long ld = pp->ld;
-    double* const Cg = pp->C;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const int prow = pi16(r);
-    const int nwave = 8;
-    const d4 zero = {0, 0, 0, 0};
-    if (nt == 0) { if (threadIdx.x == 0) dnode[pp->node] = 0.0; return; }
-    const int ntl = nt * (nt + 1) / 2;
-    double* const inv = lds + (long)ntl * FT_SZ;
-    auto tix = [&](int i, int j) -> int { return i * (i + 1) / 2 + j; };
-    // ---- A. lower tiles of C into LDS: 16-byte chunks, four in flight per thread
-    {
-        constexpr int G = 4;
-        const int total = ntl * 128;
-        for (int e0 = threadIdx.x; e0 < total; e0 += G * 512) {
-            d2 v[G];
-            int dst[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                int e = e0 + g * 512;
-                e = e < total ? e : total - 1;
-                const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
-                int i = 0;
-                while ((i + 1) * (i + 2) / 2 <= tile) ++i;
-                const int j = tile - i * (i + 1) / 2;
-                v[g] = gld2(Cg + (long)(i * 16 + row) * ld + j * 16 + c2);
-                dst[g] = tile * FT_SZ + row * FT_LD + c2;
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) if (e0 + g * 512 < total) *(d2*)(lds + dst[g]) = v[g];
-        }
-    }
-    __syncthreads();
-    // ---- B. Cholesky, left-looking over the column tiles (k_front phase B with every column a panel column)
-    double logacc = 0.0;
-    for (int jb = 0; jb < nt; ++jb) {
-        if (jb > 0) {
-            for (int ib = jb + wave; ib < nt; ib += nwave) {
-                d4 u0 = zero, u1 = zero;
-                for (int kb = 0; kb < jb; ++kb) {
-                    const d4 a = *(const d4*)(lds + (long)tix(jb, kb) * FT_SZ + prow * FT_LD + 4 * q);
-                    const d4 b = *(const d4*)(lds + (long)tix(ib, kb) * FT_SZ + r * FT_LD + 4 * q);
-                    u0 = mfma16(a[0], b[0], u0); u1 = mfma16(a[1], b[1], u1);
-                    u0 = mfma16(a[2], b[2], u0); u1 = mfma16(a[3], b[3], u1);
-                }
-                d4* tp = (d4*)(lds + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
-                *tp = *tp - (u0 + u1);
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-            double a[16], m[16];
-            double* dt = lds + (long)tix(jb, jb) * FT_SZ;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
-            bool bad = false;
-            logacc += chol16_inv(a, m, r, bad, nullptr);
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
-                    *(d2*)(inv + jb * FT_SZ + lane * FT_LD + k) = d2{m[k], m[k + 1]};
-                    gst2(pp->invd + (long)jb * 256 + lane * 16 + k, d2{m[k], m[k + 1]});
-                }
-                if (bad && lane == 0) atomicMax(err, pp->node + 1);
-            }
-        }
-        __syncthreads();
-        {
-            const d4 ia = *(const d4*)(inv + jb * FT_SZ + prow * FT_LD + 4 * q);
-            for (int ib = jb + 1 + wave; ib < nt; ib += nwave) {
-                d4* tp = (d4*)(lds + (long)tix(ib, jb) * FT_SZ + r * FT_LD + 4 * q);
-                const d4 b = *tp;
-                d4 x0 = mfma16(ia[0], b[0], zero), x1 = mfma16(ia[1], b[1], zero);
-                x0 = mfma16(ia[2], b[2], x0); x1 = mfma16(ia[3], b[3], x1);
-                *tp = x0 + x1;
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) dnode[pp->node] = 2.0 * logacc;
-    // ---- C. the factor back to global memory (32 bytes per lane, one tile per wave and step)
-    for (int t = wave; t < ntl; t += nwave) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= t) ++i;
-        const int j = t - i * (i + 1) / 2;
-        gst4(Cg + (long)(i * 16 + r) * ld + j * 16 + 4 * q, *(const d4*)(lds + (long)t * FT_SZ + r * FT_LD + 4 * q));
-    }
-    // ---- D. rows of Ut: X = Ut Lc^-T, 16 rows per wave, solved tiles chained in registers (k_trsm_rows2 with this LDS image)
-    for (int t = wave; t < nat; t += nwave) {
-        double* xp = pp->Ut + (long)(t * 16 + r) * ld + 4 * q;
-        d4 x[NTMAX];
-#pragma unroll
-        for (int jb = 0; jb < NTMAX; ++jb) x[jb] = (jb < nt) ? gld4(xp + jb * 16) : zero;
-#pragma unroll
-        for (int jb = 0; jb < NTMAX; ++jb) {
-            if (jb < nt) {
-                d4 acc = x[jb];
-                d4 u0 = zero, u1 = zero;
-#pragma unroll
-                for (int kb = 0; kb < jb; ++kb) {
-                    const d4 a = *(const d4*)(lds + (long)(jb * (jb + 1) / 2 + kb) * FT_SZ + prow * FT_LD + 4 * q);
-                    u0 = mfma16(a[0], x[kb][0], u0); u1 = mfma16(a[1], x[kb][1], u1);
-                    u0 = mfma16(a[2], x[kb][2], u0); u1 = mfma16(a[3], x[kb][3], u1);
-                }
-                if (jb > 0) acc -= u0 + u1;
-                const d4 ia = *(const d4*)(inv + jb * FT_SZ + prow * FT_LD + 4 * q);
-                d4 y0 = mfma16(ia[0], acc[0], zero), y1 = mfma16(ia[1], acc[1], zero);
-                y0 = mfma16(ia[2], acc[2], y0); y1 = mfma16(ia[3], acc[3], y1);
-                const d4 xx = y0 + y1;
-                x[jb] = xx;
-                gst4(xp + jb * 16, xx);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 //  Fused prior cascade ("regular" trees: every non-leaf level has the same knot-block width
 //  CWT*16 and all leaves sit on the last level).
 //

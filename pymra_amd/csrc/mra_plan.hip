@@ -680,9 +680,6 @@ static void build_leaf(mra_plan* pl, const double* y) {
         {
             // fused row solve + update (k_leaf_solve_update) for the leaves with at most 8 observation tiles, in the same order
             std::vector<LeafSolveProb> sp;
-            std::vector<LeafFactorProb> lf;
-            std::vector<PanelProb> pcp;
-            std::vector<Trsm2Prob> ttp;                       // rows of Tt only (Ut is solved by k_leaf_factor)
             std::vector<GemmProb> up;
             int nat_max = 0;
             for (int pass = 0; pass < 2; ++pass)
@@ -701,22 +698,10 @@ static void build_leaf(mra_plan* pl, const double* y) {
                     q.ldL = nop; q.ldx = nop; q.ldw = pl->ldw;
                     q.nt = nop / 16; q.nrt = (int)(nr / 16); q.nat = na / 16; q.zt = (na - MRA_YB) / 16;
                     sp.push_back(q);
-                    lf.push_back(LeafFactorProb{Pn, pl->leafInv.p + pl->leaf_ioff[t], Pn + (size_t)nop * nop, nop, nop / 16, na / 16, i});
-                    pcp.push_back(pc[t]);
-                    ttp.push_back(Trsm2Prob{Pn, pl->leafInv.p + pl->leaf_ioff[t], Pn + (size_t)(nop + na) * nop, pl->var.p + r0, nop, nop, nop / 16,
-                                            (int)(nr / 16), 0, -1.0, nullptr, nullptr, 0, 0});
                     up.push_back(gu[t]);
                     if (small) nat_max = std::max(nat_max, q.nat);
                 }
             pl->gLeafSolve.upload(sp);
-            pl->gLeafFactor.upload(lf);
-            pl->gLeafCholCPlain.upload(pcp);
-            pl->gLeafTrsmTtPlain.upload(ttp);
-            {
-                const int ntm = pl->leaf_max_nop / 16;        // k_leaf_factor takes every leaf when the largest has at most 10 observation tiles
-                pl->leaf_factor_lds = (size_t)(ntm * (ntm + 1) / 2 + ntm) * FT_SZ * sizeof(double);
-            }
-            pl->gLeafUpdatePlain.upload(up);
             {
                 std::vector<long> lr0(nl);
                 std::vector<unsigned char> lup(nl);
@@ -1191,31 +1176,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
             const int ntl = pl->leaf_max_nop / 16;
             if (ntl <= 12) {
-                // few leaves per CU (a rank of an 8-way shard): the small leaves' Cholesky runs in LDS, one workgroup per leaf, with
-                // the Ut row solve behind it in the same launch (k_leaf_factor); otherwise one wave per matrix (k_chol_wave)
-                solve_fused = fused && pred && pl->use_leaf_solve && pl->leaf_solve_ok &&
-                              (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(2 * pl->n_cu));
-                const bool coop = fused && pl->use_leaf_factor && nl > 0 && ntl <= 10 && pl->leaf_factor_lds <= 160 * 1024 &&
-                                  (solve_fused || (!pred && nl <= (size_t)(2 * pl->n_cu)));
-                if (coop) {
-                    // ALL leaves in one launch (a second launch for the few leaves with more than 128 observations would put its own
-                    // dependency chain behind this one)
-                    ensure_big_lds(pl, {(const void*)k_leaf_factor<10>});
-                    hipLaunchKernelGGL((k_leaf_factor<10>), dim3((unsigned)nl), dim3(512), pl->leaf_factor_lds, pl->stream, pl->gLeafFactor.p, pl->dnode.p, pl->errflag.p);
-                } else {
-                    hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
-                }
+                hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
-                if (fused && coop) {
-                    // every leaf's Ut rows are solved already; leaves with more than 128 observations (not taken by the fused solve + update)
-                    // still need their Tt rows
-                    const size_t ns = pl->n_trsm_small;
-                    if (pred && nl > ns) launch_trsm2(pl, pl->gLeafTrsmTtPlain.p + ns, nl - ns, ntl, pl->leaf_max_rows / 16, 4);
-                } else if (fused) {
+                if (fused) {
                     // with the fused row solve + update the small leaves only need their Ut rows solved here
                     // (one 8-wave workgroup per CU: a gain when a CU sees at most two leaves - 1.21 -> 1.13 ms on an eighth of C3 -
                     // and a loss from four per CU on - 1.87 -> 1.90 ms on a quarter - where the update rides in the predictive
                     // cascade at three workgroups per CU)
+                    solve_fused = pred && pl->use_leaf_solve && pl->leaf_solve_ok &&
+                                  (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(2 * pl->n_cu));
                     const Trsm2Prob* base = pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p;
                     const size_t ns = pl->n_trsm_small;
                     const int mts = (pred && !solve_fused) ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
@@ -1707,7 +1676,6 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
     if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
     if (option == 8) { pl->use_pred_update = value != 0; return MRA_OK; }
-    if (option == 9) { pl->use_leaf_factor = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
         // wide leaf-residual shape); bits 1, 2, 4 (no Ut scatter / no W stores / constant instead of the kernel) give WRONG results
@@ -1734,7 +1702,6 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 6: *value = pl->use_leaf_gemm ? (pl->leaf_gemm_update ? 2 : 1) : 0; break;
         case 7: *value = pl->leaf_solve_mode; break;
         case 8: *value = pl->use_pred_update; break;
-        case 9: *value = pl->use_leaf_factor; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
     }
@@ -1751,8 +1718,7 @@ int mra_plan_prepare(mra_plan* pl, int64_t* n_kernels) {
         struct Guard { mra_plan* p; ~Guard() { p->prepare_only = false; } } guard{pl};
         launch_trsm2(pl, nullptr, 0, 1, 0, 1);
         ensure_big_lds(pl, {(const void*)k_front<true>, (const void*)k_front<false>, (const void*)k_parent_front<2>, (const void*)k_parent_front<4>,
-                            (const void*)k_parent_front<8>, (const void*)k_parent_front<12>, (const void*)k_leaf_solve_update<8, 13, true>,
-                            (const void*)k_leaf_factor<10>});
+                            (const void*)k_parent_front<8>, (const void*)k_parent_front<12>, (const void*)k_leaf_solve_update<8, 13, true>});
         if (pl->regular) {
             CascadeArgs ar{};
             ar.n_wg = 1;

@@ -208,11 +208,6 @@ struct mra_plan {
     std::vector<long> bigM[2], bigN[2];
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
     DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
-    DevVec<LeafFactorProb> gLeafFactor;   // k_leaf_factor (Cholesky in LDS + Ut row solve), same order
-    DevVec<PanelProb> gLeafCholCPlain;    // k_chol_wave descriptors in that order
-    DevVec<Trsm2Prob> gLeafTrsmTtPlain;   // row solve of the Tt rows alone, same order (leaves whose Ut k_leaf_factor has solved)
-    bool use_leaf_factor = true;
-    size_t leaf_factor_lds = 0;
     DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
     bool use_leaf_solve = true, leaf_solve_ok = false;
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade

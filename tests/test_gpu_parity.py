@@ -351,8 +351,8 @@ def test_single_launch_chains_equal_per_level_launches(hip, name):
     the launch sequences / kernels they replace."""
     cs = K.load_case(name)
     pl, lik, mean, var = run_hip(hip, cs)
-    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (7, 1, 9, 0), (9, 0), (8, 0), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0, 9, 0)):
-        pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1); pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(9, 1)
+    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (8, 0), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0)):
+        pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1); pl.set_option(7, 2); pl.set_option(8, 1)
         for o, v in zip(opts[::2], opts[1::2]):
             pl.set_option(o, v)
         pl.run(True, True)
@@ -360,13 +360,6 @@ def test_single_launch_chains_equal_per_level_launches(hip, name):
         m2, v2 = pl.predict()
         assert abs(d + u - lik) <= 1e-12 * abs(lik), opts
         assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10, opts
-    # likelihood-only passes: the leaf Cholesky in LDS with the Ut solve behind it (MRA_OPT_LEAF_FACTOR, taken when a CU sees at most
-    # two leaves) against one wave per matrix + separate row solve
-    for v in (1, 0):
-        pl.set_option(9, v)
-        pl.run(True, False)
-        d, u = pl.likelihood()
-        assert abs(d + u - lik) <= 1e-12 * abs(lik), ("likelihood only, MRA_OPT_LEAF_FACTOR", v)
     pl.close()
 
 
