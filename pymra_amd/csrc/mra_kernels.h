@@ -2217,6 +2217,208 @@ _Pragma("unroll") \
 }
 
 // ------------------------------------------------------------------------------------------------
+//  Predictive cascade of DEEP trees with 64-wide blocks (five to eight non-leaf levels of four tiles: BASELINE config 5,
+//  M = 8, r0 = 64), upper half.  A row tile of such a tree has 32 basis tiles: twice the register file.  The walk is split:
+//      k_predict_hi      the four deepest levels with their 16 tiles in registers, X_m = W~^m Lt_m^-T in place (MRANode.py:504-511),
+//                        the updates among those four levels in registers, then ONE sweep over the row's coarser tiles
+//                        (levels < nl-4 and the y block):  w -= sum_{m >= nl-4} X_m Zt_m[w's rows]^T, read and written once;
+//      k_predict_cascade the remaining (at most four) coarse levels, as for any shallow tree.
+//  Level by level the same work re-reads and re-writes the coarse columns once per level: 129 GB at config 5 against 35 GB here.
+//  Node operands do not fit LDS (Zt of a level-7 node: 232 KB), so they stream through a double-buffered stage in chunks of
+//  16 tiles (32 KB): the solve operands of a level, the Zt rows of one finer-on-coarser level pair, or the Zt rows of all four
+//  levels for one coarse tile - 40 to 64 MFMAs per wave, chunk and barrier.
+// ------------------------------------------------------------------------------------------------
+struct PredHiArgs {
+    PredLevel hi[4];          // the four deepest non-leaf levels, hi[h] = level nl - 4 + h
+    double* W;                // in: whitened basis after the leaf update; out: columns [levels < nl - 4 | y block] updated in place
+    double* var;              // in: leaf part (clamped at 0 here), out: + sum_h |X_h|^2
+    long ldw;
+    int coff_hi[4];           // W column of hi level h
+    int col_low;              // W column of the first coarse tile (levels nl-5 .. 0 and the y block are contiguous from here)
+    int n_low;                // coarse tiles, y tile included: (nl - 4) * 4 + 1
+    int lev0;                 // nl - 4: position of hi level 0 in a tile's chain
+    const long* tile_row0;
+    const int* tile_chain;
+    const long* wg_tile0;     // per workgroup: first tile and number of tiles (<= 4), all sharing one chain
+    const int* wg_ntiles;
+};
+
+// the 16-byte pieces of a 16-tile chunk this thread stages: piece i is row (chunk >> 3), doubles c2, c2+1 of tile tsel + 2 i
+#define MRA_PH_ISSUE_Z(F0, N0, A0, F1, N1, A1, F2, N2, A2, F3, N3, A3) do { \
+        pre[0] = gld2((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + sjb0 * 16 + sc2); \
+        pre[1] = gld2((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + (sjb0 + 2) * 16 + sc2); \
+        pre[2] = gld2((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + sjb0 * 16 + sc2); \
+        pre[3] = gld2((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + (sjb0 + 2) * 16 + sc2); \
+        pre[4] = gld2((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + sjb0 * 16 + sc2); \
+        pre[5] = gld2((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + (sjb0 + 2) * 16 + sc2); \
+        pre[6] = gld2((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + sjb0 * 16 + sc2); \
+        pre[7] = gld2((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + (sjb0 + 2) * 16 + sc2); \
+} while (0)
+// solve operands of hi level H: tiles 0..5 = strictly-lower tiles of Lt ((1,0) (2,0) (2,1) (3,0) (3,1) (3,2)), 6..9 = inverted diagonal blocks
+#define MRA_PH_ISSUE_T(H) do { \
+_Pragma("unroll") \
+        for (int i = 0; i < 5; ++i) { \
+            const int tile = stile0 + 2 * i; \
+            const double* src; \
+            if (tile < 6) { \
+                const int jb = tile < 1 ? 1 : (tile < 3 ? 2 : 3), kb = tile - jb * (jb - 1) / 2; \
+                src = Fh[H] + (long)(jb * 16 + srow) * nfh[H] + kb * 16 + sc2; \
+            } else src = invh[H] + (long)(tile - 6) * 256 + srow * 16 + sc2; \
+            pre[i] = gld2(src); \
+        } \
+} while (0)
+#define MRA_PH_WRITE(BUF, NPIECE) do { \
+_Pragma("unroll") \
+        for (int i = 0; i < (NPIECE); ++i) *(d2*)((BUF) + (long)(stile0 + 2 * i) * 256 + srow * 16 + sc2) = pre[i]; \
+} while (0)
+
+template <int CWT>        // = 4 (a template so that only the translation unit that launches it instantiates it)
+__global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
+    static_assert(CWT == 4, "k_predict_hi is written for 64-wide blocks");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* const buf0 = lds;
+    double* const buf1 = lds + 16 * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const long t0 = ar.wg_tile0[blockIdx.x];
+    const int nt_wg = ar.wg_ntiles[blockIdx.x];
+    if (nt_wg == 0) return;
+    const bool active = wave < nt_wg;
+    const long t = t0 + (active ? wave : 0);
+    const int prow = pi16(r);
+    const d4 zero = {0, 0, 0, 0};
+    const long myrow = ar.tile_row0[t] + r;
+    const int* chain = ar.tile_chain + t0 * 8 + ar.lev0;
+    double* const wrow = ar.W + myrow * ar.ldw + 4 * q;
+    // staging role of this thread inside a 16-tile chunk
+    const int stile0 = threadIdx.x >> 7, sjb0 = stile0, schunk = threadIdx.x & 127, srow = schunk >> 3, sc2 = (schunk & 7) << 1;
+    const double* Fh[4];
+    const double* invh[4];
+    long nfh[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const long slot = chain[h];
+        nfh[h] = ar.hi[h].nf;
+        Fh[h] = ar.hi[h].F + slot * nfh[h] * nfh[h];
+        invh[h] = ar.hi[h].invF + slot * 4 * 256;
+    }
+    d2 pre[8];
+    d4 w[4][4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) w[h][jb] = *(const d4*)(wrow + ar.coff_hi[h] + jb * 16);
+    double ssq = 0.0;
+    const int fo = prow * 16 + 4 * q;                      // this lane's fragment inside a staged tile
+    // ---- the four deepest levels, deepest first; chunk c lives in buffer c & 1
+    MRA_PH_ISSUE_T(3);
+    MRA_PH_WRITE(buf0, 5);
+    __syncthreads();
+#define MRA_PH_SOLVE(H, BUF) do { \
+        if (active) { \
+            d4 x[4]; \
+_Pragma("unroll") \
+            for (int jb = 0; jb < 4; ++jb) { \
+                d4 acc = w[H][jb]; \
+                d4 upd = zero; \
+_Pragma("unroll") \
+                for (int kb = 0; kb < 4; ++kb) { \
+                    if (kb < jb) { \
+                        const d4 a = *(const d4*)((BUF) + (jb * (jb - 1) / 2 + kb) * 256 + fo); \
+_Pragma("unroll") \
+                        for (int j = 0; j < 4; ++j) upd = mfma16(a[j], x[kb][j], upd); \
+                    } \
+                } \
+                acc -= upd; \
+                const d4 ia = *(const d4*)((BUF) + (6 + jb) * 256 + fo); \
+                d4 xx = zero; \
+_Pragma("unroll") \
+                for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], acc[j], xx); \
+                x[jb] = xx; \
+                ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3]; \
+            } \
+_Pragma("unroll") \
+            for (int jb = 0; jb < 4; ++jb) w[H][jb] = x[jb]; \
+        } \
+} while (0)
+    // w[HP][kt] -= X_H Zt_H[rows of level HP]^T : tiles (kt, jb) of the chunk
+#define MRA_PH_UPDATE(H, HP, BUF) do { \
+        if (active) { \
+_Pragma("unroll") \
+            for (int kt = 0; kt < 4; ++kt) { \
+                d4 acc = zero; \
+_Pragma("unroll") \
+                for (int jb = 0; jb < 4; ++jb) { \
+                    const d4 z = *(const d4*)((BUF) + (kt * 4 + jb) * 256 + fo); \
+_Pragma("unroll") \
+                    for (int j = 0; j < 4; ++j) acc = mfma16(z[j], w[H][jb][j], acc); \
+                } \
+                w[HP][kt] -= acc; \
+            } \
+        } \
+} while (0)
+#define MRA_PH_ISSUE_U(H, HP) MRA_PH_ISSUE_Z(Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 0, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 1, \
+                                             Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 2, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 3)
+    // level 3 (deepest)
+    MRA_PH_ISSUE_U(3, 2);  MRA_PH_SOLVE(3, buf0);      MRA_PH_WRITE(buf1, 8); __syncthreads();
+    MRA_PH_ISSUE_U(3, 1);  MRA_PH_UPDATE(3, 2, buf1);  MRA_PH_WRITE(buf0, 8); __syncthreads();
+    MRA_PH_ISSUE_U(3, 0);  MRA_PH_UPDATE(3, 1, buf0);  MRA_PH_WRITE(buf1, 8); __syncthreads();
+    MRA_PH_ISSUE_T(2);     MRA_PH_UPDATE(3, 0, buf1);  MRA_PH_WRITE(buf0, 5); __syncthreads();
+    // level 2
+    MRA_PH_ISSUE_U(2, 1);  MRA_PH_SOLVE(2, buf0);      MRA_PH_WRITE(buf1, 8); __syncthreads();
+    MRA_PH_ISSUE_U(2, 0);  MRA_PH_UPDATE(2, 1, buf1);  MRA_PH_WRITE(buf0, 8); __syncthreads();
+    MRA_PH_ISSUE_T(1);     MRA_PH_UPDATE(2, 0, buf0);  MRA_PH_WRITE(buf1, 5); __syncthreads();
+    // level 1
+    MRA_PH_ISSUE_U(1, 0);  MRA_PH_SOLVE(1, buf1);      MRA_PH_WRITE(buf0, 8); __syncthreads();
+    MRA_PH_ISSUE_T(0);     MRA_PH_UPDATE(1, 0, buf0);  MRA_PH_WRITE(buf1, 5); __syncthreads();
+    // level 0 of the four; behind it the first coarse tile's operands
+    const int n_low = ar.n_low;
+    double* const wlow = wrow + ar.col_low;
+#define MRA_PH_ISSUE_V(I) MRA_PH_ISSUE_Z(Fh[0], nfh[0], 0 + (I), Fh[1], nfh[1], 4 + (I), Fh[2], nfh[2], 8 + (I), Fh[3], nfh[3], 12 + (I))
+    MRA_PH_ISSUE_V(0);
+    d4 wl = *(const d4*)wlow;
+    MRA_PH_SOLVE(0, buf1);
+    MRA_PH_WRITE(buf0, 8);
+    __syncthreads();
+    // ---- one sweep over the coarse tiles: w_i -= sum_h X_h Zt_h[4 h + i]^T  (tile (h, jb) of the chunk)
+#pragma nounroll
+    for (int i = 0; i < n_low; ++i) {
+        const double* bufc = (i & 1) ? buf1 : buf0;
+        double* bufn = (i & 1) ? buf0 : buf1;
+        const int in = (i + 1 < n_low) ? i + 1 : i;
+        MRA_PH_ISSUE_V(in);
+        const d4 wn = *(const d4*)(wlow + in * 16);
+        if (active) {
+            d4 acc0 = zero, acc1 = zero;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const d4 z = *(const d4*)(bufc + (h * 4 + jb) * 256 + fo);
+                    if (h & 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc1 = mfma16(z[j], w[h][jb][j], acc1);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc0 = mfma16(z[j], w[h][jb][j], acc0);
+                    }
+                }
+            }
+            *(d4*)(wlow + i * 16) = wl - (acc0 + acc1);
+        }
+        wl = wn;
+        if (i + 1 < n_low) MRA_PH_WRITE(bufn, 8);
+        __syncthreads();
+    }
+    if (!active) return;
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (q == 0) {
+        const double v0 = ar.var[myrow];
+        ar.var[myrow] = (v0 > 0.0 ? v0 : 0.0) + ssq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 //  small kernels
 // ------------------------------------------------------------------------------------------------
 // W[:, Ka] = y (0 where missing), W[:, Ka+1 .. Ka+15] = 0

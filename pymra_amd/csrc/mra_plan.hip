@@ -317,6 +317,39 @@ static void build_static(mra_plan* pl) {
         if (cwt * NL > 16) ok = false;                       // register budget of the cascade kernels
         if (ok) { pl->regular = true; pl->NL = NL; pl->CWT = cwt; }
     }
+    pl->regular_hi = false;
+    if (!pl->regular && pl->shape_regular && NL >= 5 && NL <= 8) {
+        bool ok = true;
+        for (int m = 0; m < NL && ok; ++m) if (pl->cw[m] != 64) ok = false;
+        if (ok) {
+            pl->regular_hi = true; pl->NL = NL; pl->CWT = 4;
+            // row tiles of the leaves with their ancestor chains; one workgroup per leaf (<= 4 tiles) for k_predict_hi, groups of eight
+            // consecutive tiles below one level-(NL-5) node for the coarse cascade
+            std::vector<long> r0s, wg0, wg0_8;
+            std::vector<int> chains, wgn, wgn_8;
+            const int nlo = NL - 4;
+            int prev_coarse = -1;
+            for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+                const int i = pl->leaf_nodes[t];
+                int ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int a = pl->parent[i]; a >= 0; a = pl->parent[a]) ch[pl->node_level[a]] = pl->node_slot[a];
+                const int coarse = ch[nlo - 1];                          // slot of the deepest coarse level: same slot = same coarse chain
+                for (long p = pl->row0[i]; p < pl->row1[i]; p += 16) {
+                    const long k = (p - pl->row0[i]) / 16;
+                    if (k % 4 == 0) { wg0.push_back((long)r0s.size()); wgn.push_back((int)std::min<long>(4, (pl->row1[i] - p) / 16)); }
+                    if (wgn_8.empty() || wgn_8.back() == 8 || coarse != prev_coarse) { wg0_8.push_back((long)r0s.size()); wgn_8.push_back(0); }
+                    ++wgn_8.back();
+                    prev_coarse = coarse;
+                    r0s.push_back(p);
+                    for (int k2 = 0; k2 < 8; ++k2) chains.push_back(ch[k2]);
+                }
+            }
+            pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains);
+            pl->n_ftiles = (long)r0s.size();
+            pl->ft_wg0.upload(wg0); pl->ft_wgn.upload(wgn); pl->n_fwg = (long)wg0.size();
+            pl->hi_wg0_8.upload(wg0_8); pl->hi_wgn_8.upload(wgn_8); pl->n_hi_wg8 = (long)wg0_8.size();
+        }
+    }
     if (pl->regular) {
         const int cw = pl->cw[0];
         pl->fl.clear();
@@ -853,6 +886,39 @@ static void run_prior_fused(mra_plan* pl) {
     }
 }
 
+// predictive pass of a deep 64-wide tree (regular_hi): W holds the whitened basis after the leaf update
+static void run_predict_hi(mra_plan* pl) {
+    const int NL = pl->NL, nlo = NL - 4;
+    PredHiArgs hi{};
+    Work fl_hi, fl_lo;
+    for (int h = 0; h < 4; ++h) {
+        const int m = nlo + h;
+        hi.hi[h].F = pl->lev[m].F.p; hi.hi[h].invF = pl->lev[m].invF.p; hi.hi[h].nf = pl->lev[m].nf;
+        hi.coff_hi[h] = pl->coff[m];
+        fl_hi += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
+    }
+    hi.W = pl->W.p; hi.var = pl->var.p; hi.ldw = pl->ldw;
+    hi.col_low = pl->coff[nlo - 1]; hi.n_low = nlo * 4 + 1; hi.lev0 = nlo;
+    hi.tile_row0 = pl->ft_row0.p; hi.tile_chain = pl->ft_chain.p; hi.wg_tile0 = pl->ft_wg0.p; hi.wg_ntiles = pl->ft_wgn.p;
+    // W read once, its coarse columns and y block written once; var in and out
+    fl_hi.bytes = 8.0 * pl->P * (pl->ldw + (pl->ldw - pl->coff[nlo - 1]) + 2);
+    PredArgs lo{};
+    for (int m = 0; m < nlo; ++m) {
+        lo.lev[m].F = pl->lev[m].F.p; lo.lev[m].invF = pl->lev[m].invF.p; lo.lev[m].nf = pl->lev[m].nf;
+        lo.coff[m] = pl->coff[m];
+        fl_lo += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
+    }
+    lo.deep = lo.lev[nlo - 1];
+    lo.W = pl->W.p; lo.mean = pl->mean.p; lo.var = pl->var.p; lo.ldw = pl->ldw; lo.ycol = pl->Ka;
+    lo.tile_row0 = pl->ft_row0.p; lo.tile_chain = pl->ft_chain.p; lo.wg_tile0 = pl->hi_wg0_8.p; lo.wg_ntiles = pl->hi_wgn_8.p;
+    lo.n_wg = pl->n_hi_wg8; lo.nl = nlo;
+    fl_lo.bytes = 8.0 * pl->P * ((pl->ldw - pl->coff[nlo - 1]) + 3);
+    const size_t lds_low = (size_t)(4 * 3 / 2 + 4 + ((nlo - 1) * 4 + 1) * 4) * 2048;
+    // two launches; the kernel timer brackets both (the coarse share is reported with them: they are one pass over W's coarse half)
+    KTimer kt(pl, KF_PRED_UPDATE, fl_hi + fl_lo);
+    launch_predict_hi(pl, hi, lo, lds_low);
+}
+
 static void run_predict_fused(mra_plan* pl) {
     PredArgs ar{};
     for (int m = 0; m < pl->NL; ++m) {
@@ -999,8 +1065,10 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
         pl->side_pending = false;
     }
     const bool fusedp = pl->regular && pl->use_fused && !pl->host_cov;
+    const bool hip_ = !fusedp && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
     if ((pl->run_flags & MRA_RUN_PREDICT) && fusedp) run_predict_fused(pl);
-    if ((pl->run_flags & MRA_RUN_PREDICT) && !fusedp) {
+    if ((pl->run_flags & MRA_RUN_PREDICT) && hip_) run_predict_hi(pl);
+    if ((pl->run_flags & MRA_RUN_PREDICT) && !fusedp && !hip_) {
         for (int m = pl->n_levels - 1; m >= 0; --m) {
             LevelData& lv = pl->lev[m];
             const size_t nn = lv.nodes.size();
@@ -1041,7 +1109,8 @@ static void finish_run(mra_plan* pl) {
             HIP_TRY(hipHostGetDevicePointer((void**)&pl->host_res_dev, pl->host_res, 0));
         }
         hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->host_res_dev, up, below, pl->errflag.p);
-        if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov))
+        const bool hi_path = !(pl->regular && pl->use_fused && !pl->host_cov) && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
+        if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov) && !hi_path)
             hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
                                pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
     }
@@ -1740,7 +1809,8 @@ int mra_plan_prepare(mra_plan* pl, int64_t* n_kernels) {
 int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int* launches, double* ms, double* flops) {
     if (!pl || which < 0 || which >= KF_COUNT) return MRA_ERR_INVALID;
     const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
-    if (name && name_cap > 0) { strncpy(name, kfam_name[fused ? 0 : 1][which], name_cap - 1); name[name_cap - 1] = 0; }
+    const bool hi_path = !fused && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
+    if (name && name_cap > 0) { strncpy(name, kfam_name[fused ? 0 : (hi_path ? 2 : 1)][which], name_cap - 1); name[name_cap - 1] = 0; }
     if (launches) *launches = pl->kstat[which].launches;
     if (ms) *ms = pl->kstat[which].ms;
     if (flops) *flops = pl->kstat[which].flops;

@@ -63,8 +63,8 @@ enum KFam {
     KF_LEAF_UPDATE, KF_FRONT_CHOL, KF_FRONT_SCHUR, KF_PRED_TRSM, KF_PRED_UPDATE, KF_MISC, KF_COUNT
 };
 // family names = the kernels that actually run (rocprofv3 kernel names), by path: [0] fused cascades on regular trees,
-// [1] general level-by-level path.  tools/summarize_profiles.py maps the trace's kernel names onto the same strings.
-static const char* kfam_name[2][KF_COUNT] = {
+// [1] general level-by-level path, [2] level-by-level prior and fronts with the two-kernel predictive cascade of deep 64-wide trees.  tools/summarize_profiles.py maps the trace's kernel names onto the same strings.
+static const char* kfam_name[3][KF_COUNT] = {
     {"k_gemm_nt_lds<COV> prior residual (unused on the fused path)",
      "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)",
      "k_prior_cascade row pass (W of all levels, Ut scatter)",
@@ -88,6 +88,18 @@ static const char* kfam_name[2][KF_COUNT] = {
      "k_gemm_nt<SUB> front Schur complement",
      "k_trsm_rows2 predict X = W Lt^-T per level",
      "k_gemm_nt_lds<SUB> predict update per level",
+     "small kernels (k_assemble, k_gather_kinv, k_leaf_moments, k_sum_dnode, ...)"},
+    {"k_gemm_nt_lds<COV> prior residual per level",
+     "k_panel_chol prior kInv Cholesky per level",
+     "k_trsm_rows2 prior W = R L^-T per level",
+     "k_leaf_gemm<COV> leaf residual V[S,o] and C",
+     "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
+     "k_gemm_nt<SET> / k_parent_front leaf or parent SYRK",
+     "k_gemm_nt_lds<SUB> leaf update W[S,anc] -= Tt^T Ut",
+     "k_front / k_panel_chol front partial Cholesky",
+     "k_gemm_nt<SUB> front Schur complement",
+     "k_predict_cascade (the four coarse levels of a deep tree)",
+     "k_predict_hi (four deepest levels in registers + one sweep over the coarse columns)",
      "small kernels (k_assemble, k_gather_kinv, k_leaf_moments, k_sum_dnode, ...)"}};
 
 // Work of a launch (or a family of launches): algorithmic flops with TRUE sizes (true ranks, true observation counts, a
@@ -235,6 +247,12 @@ struct mra_plan {
     double by_leaf_ut = 0, by_leaf_tt = 0, by_leaf_c = 0;     // bytes of all leaves' Ut / Tt (= V) / C blocks
     std::vector<long> anc_rank;          // per node: sum of the TRUE ranks of its ancestors
     // fused ("regular tree") path
+    // deep trees with 64-wide blocks (5 - 8 non-leaf levels of four tiles: BASELINE config 5): too many tiles per row for the one-kernel
+    // cascades; the predictive pass runs as k_predict_hi (four deepest levels) + k_predict_cascade (coarse levels)
+    bool regular_hi = false;
+    DevVec<long> hi_wg0_8;
+    DevVec<int> hi_wgn_8;
+    long n_hi_wg8 = 0;
     bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true, leaf_gemm_update = false;
     int dbg = 0;
     int NL = 0, CWT = 0;
@@ -308,3 +326,4 @@ void launch_knot_chain_d2(mra_plan* pl, const KnotChainArgs& ka);
 static inline void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) { if (pl->d == 1) launch_cascade_d1(pl, ar); else launch_cascade_d2(pl, ar); }
 static inline void launch_knot_chain(mra_plan* pl, const KnotChainArgs& ka) { if (pl->d == 1) launch_knot_chain_d1(pl, ka); else launch_knot_chain_d2(pl, ka); }
 void launch_predict_any(mra_plan* pl, const PredArgs& ar, size_t lds);
+void launch_predict_hi(mra_plan* pl, const PredHiArgs& hi, const PredArgs& low, size_t lds_low);

@@ -571,3 +571,37 @@ def test_leaves_without_any_observation(hip):
         assert abs(d + u - lik) <= 1e-12 * abs(lik), opts
         assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10, opts
     pl.close()
+
+
+@pytest.mark.parametrize("n,r,M,oracle", [(256, 64, 5, True), (512, 64, 6, True), (1024, 64, 7, False)])
+def test_deep_wide_trees_two_kernel_predictive_cascade(hip, n, r, M, oracle):
+    """Trees with 64-wide blocks and 5 - 8 non-leaf levels (BASELINE config 5 is the 8-level one, tests/test_gpu_fullsize.py) have
+    too many tiles per row for the one-kernel cascades: their predictive pass is k_predict_hi (four deepest levels in registers, one
+    sweep over the coarse columns) + k_predict_cascade (coarse levels).  Against the level-by-level kernels at every depth and
+    against the CPU oracle where it finishes in seconds."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    np.random.seed(23)
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y = np.random.normal(size=(n * n, 1))
+    y_obs = np.where(np.random.uniform(size=(n * n, 1)) < 0.4, y, np.nan)
+    topo = build_topology(locs, r, M, 4)
+    assert topo.n_levels == M + 1 and np.all(np.asarray(topo.cw)[:M] == 64)
+    spec = mt.KernelSpec(mt.KIND_MATERN32, 0.25, 1.2)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=2e-2))
+    pl, lik, mean, var = run_hip(hip, cs)
+    assert any("k_predict_hi" in k["name"] and k["launches"] for k in pl.kernel_stats())
+    pl.set_option(2, 0)                                    # level-by-level predictive pass
+    pl.run(True, True)
+    assert not any("k_predict_hi" in k["name"] for k in pl.kernel_stats())
+    d, u = pl.likelihood()
+    m2, v2 = pl.predict()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
+    assert np.max(np.abs(m2 - mean)) < 1e-10 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10
+    pl.close()
+    if oracle:
+        ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
+        assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+        assert np.max(np.abs(mean - ref["mean"])) < 1e-9
+        assert K.rel(np.sqrt(var), ref["sd"]) < 1e-8
