@@ -109,24 +109,56 @@ def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
                                                                 if secs_1t else None)}}
 
 
-def mle_throughput(pl, c, kind, evals=24):
-    """Nelder-Mead over the range parameter on the resident plan (README.md:96-104, tests/test-param-est.py:81-123):
-    every objective call is one likelihood-only device pass with new kernel parameters."""
+def gp_sample_rff(c, l_true, seed=12345, n_feat=1024):
+    """A Matern-3/2 Gaussian-process sample on the n x n grid of `c` by random Fourier features ("a smoother
+    variant (random-Fourier-feature GP sample, same seed) may be added"): f(x) = sqrt(2 sig / D) sum_k cos(w_k . x + b_k) with w_k
+    from the kernel's spectral measure (a bivariate Student-t with 2 nu = 3 degrees of freedom, scale 1 / l) and b_k ~ U(0, 2 pi).
+    On a grid cos(wx x_i + wy y_j + b) separates into outer products, so the whole field is two D-column GEMMs."""
+    rng = np.random.RandomState(seed)
+    n = c["n"]
+    g = np.linspace(0.0, 1.0, n)
+    z = rng.normal(size=(n_feat, 2))
+    u = rng.chisquare(3.0, size=n_feat)
+    w = z * np.sqrt(3.0 / u)[:, None] / l_true             # Matern nu = 3/2, range l_true (MRATools.Matern32: exp(-sqrt(3) D / l) (1 + sqrt(3) D / l))
+    b = rng.uniform(0.0, 2.0 * np.pi, size=n_feat)
+    ax = np.outer(g, w[:, 0]) + b[None, :]                  # x index i
+    ay = np.outer(g, w[:, 1])                               # y index j
+    f = np.cos(ay) @ np.cos(ax).T - np.sin(ay) @ np.sin(ax).T        # F[j][i]: x fastest, as genLocations2d orders the rows
+    return (np.sqrt(2.0 * c["sig"] / n_feat) * f).reshape(-1, 1), rng
+
+
+def mle_throughput(pl, c, kind, y_obs, l_true=0.2, max_evals=80):
+    """End-to-end MLE of the range parameter on the resident plan, as README.md:96-104 / tests/test-param-est.py:81-123 do it with
+    a new MRATree per call: Nelder-Mead from kappa_0 = 0.3 with xatol 1e-3 on -2 loglik = d + u (MRATree.getLikelihood), every
+    objective call one likelihood-only device pass with new kernel parameters.  The data are a GP sample of the same kernel
+    family with range l_true (random Fourier features) plus N(0, R) noise on the benchmark's observation mask, so the optimiser
+    has an interior optimum to converge to (on the iid-noise data of the throughput recipe it only walks to the lower bound)."""
     import scipy.optimize as opt
+    f, rng = gp_sample_rff(c, l_true)
+    mask = np.isfinite(np.asarray(y_obs).reshape(-1, 1))
+    y_gp = np.where(mask, f + np.sqrt(c["R"]) * rng.normal(size=f.shape), np.nan)
+    pl.set_obs(y_gp, c["R"])
     calls = []
 
     def obj(p):
-        pl.set_kernel(kind, float(abs(p[0])) + 1e-3, c["sig"], 1.0)
+        kappa = float(abs(p[0])) + 1e-3
+        pl.set_kernel(kind, kappa, c["sig"], 1.0)
         pl.run(True, False)
         d, u = pl.likelihood()
-        calls.append(d + u)
+        calls.append((kappa, d + u))
         return d + u
     t0 = time.perf_counter()
-    res = opt.minimize(obj, [c["l"]], method="nelder-mead", options={"xatol": 1e-3, "maxfev": evals, "disp": False})
+    res = opt.minimize(obj, [c["l"]], method="nelder-mead", options={"xatol": 1e-3, "maxfev": max_evals, "disp": False})
     dt = time.perf_counter() - t0
+    k_hat = float(abs(res.x[0])) + 1e-3
+    out = {"data": "Matern32 GP sample by %d random Fourier features, range %.3g, + N(0, R) noise, benchmark mask" % (1024, l_true),
+           "kappa_true": l_true, "kappa_start": c["l"], "kappa_hat": k_hat, "converged": bool(res.success),
+           "objective_evaluations": len(calls), "seconds_to_convergence": dt, "evaluations_per_s": len(calls) / dt,
+           "ms_per_evaluation": 1e3 * dt / len(calls), "objective_at_start": calls[0][1], "objective_at_kappa_hat": float(res.fun),
+           "interior_optimum": bool(0.02 < k_hat < 5.0 and res.fun < calls[0][1])}
+    pl.set_obs(y_obs, c["R"])                              # back to the throughput recipe's data
     pl.set_kernel(kind, c["l"], c["sig"], 1.0)
-    return {"objective_evaluations": len(calls), "seconds": dt, "evaluations_per_s": len(calls) / dt,
-            "ms_per_evaluation": 1e3 * dt / len(calls), "kappa_start": c["l"], "kappa_last": float(abs(res.x[0])) + 1e-3}
+    return out
 
 
 def main():
@@ -137,6 +169,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--likelihood-only", action="store_true")
+    ap.add_argument("--mle", action="store_true", help="add the end-to-end Nelder-Mead MLE block (always on for --config c5)")
     ap.add_argument("--allow-gloo-fallback", action="store_true",
                     help="with --exchange rccl: if RCCL cannot initialise, re-plan onto the host/gloo exchange instead of failing "
                          "(the line then carries \"exchange_fallback\": true)")
@@ -339,8 +372,8 @@ def main():
             "roofline": roof,
             "host": {"input_synthesis_s": t1 - t0, "tree_build_s": t2 - t1, "plan_and_upload_s": t3 - t2},
         }
-    if rank == 0 and world == 1 and args.config == "c5":
-        out["mle"] = mle_throughput(pl, c, kind)
+    if rank == 0 and world == 1 and (args.config == "c5" or args.mle):
+        out["mle"] = mle_throughput(pl, c, kind, y_obs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, locs, y_obs, c)
         # end-to-end constructor wall-clock of the drop-in API (host tree build + H2D + device pass + D2H)

@@ -199,7 +199,7 @@ struct GemmProb {
     const int* idxA;
     int sym_diag;
 };
-struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; };
+struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; int neg; };   // neg: the segment is SUBTRACTED (k_gemm_nt only)
 
 enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
 
@@ -319,31 +319,55 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__
     const int pnseg = pp->nseg;
     const GemmSeg* segs = pp->segs;
     const int nseg = pnseg > 0 ? pnseg : 1;
-    for (int sg = 0; sg < nseg; ++sg) {
-        const double *Ap, *Bp;
-        long lda, ldb;
-        int K;
-        if (pnseg > 0) { const GemmSeg* g = segs + sg; Ap = g->A; Bp = g->B; lda = g->lda; ldb = g->ldb; K = g->K; }
-        else { Ap = pp->A; Bp = pp->B; lda = pp->lda; ldb = pp->ldb; K = pp->K; }
-        // unconditional global loads one K-step ahead of the MFMAs (rows that do not exist read a valid
-        // row and are zeroed by a select): branches around loads force s_waitcnt vmcnt(0) in the loop
-        const double* a0p = Ap + (long)(m0 + r) * lda + 4 * q;
-        const double* a1p = mv1 ? a0p + 16 * lda : a0p;
-        const double* b0p = Bp + (long)(bz0 ? 0 : br0) * ldb + 4 * q;
-        const double* b1p = Bp + (long)(bz1 ? 0 : br1) * ldb + 4 * q;
-        d4 na0 = zero, na1 = zero, nb0 = zero, nb1 = zero;
-        if (K > 0) { na0 = gld4(a0p); na1 = gld4(a1p); nb0 = gld4(b0p); nb1 = gld4(b1p); }
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            const d4 a0 = na0, a1 = mv1 ? na1 : zero, b0 = bz0 ? zero : nb0, b1 = bz1 ? zero : nb1;
-            const int kn = (k0 + 16 < K) ? k0 + 16 : k0;
-            na0 = gld4(a0p + kn); na1 = gld4(a1p + kn); nb0 = gld4(b0p + kn); nb1 = gld4(b1p + kn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                c00 = mfma16(a0[j], b0[j], c00);
-                c01 = mfma16(a0[j], b1[j], c01);
-                c10 = mfma16(a1[j], b0[j], c10);
-                c11 = mfma16(a1[j], b1[j], c11);
+    // The K dimension is a flat sequence of (segment, 16-column step) pairs: the operands of step i+1 are in flight while step i is on
+    // the MFMA pipe ACROSS segment boundaries too.  (Segments are short when they are the leaves' Ut blocks - 32 observations at
+    // config 5, two steps - and a prefetch pipeline that restarts in every segment spends most of its time waiting for loads.)
+    // Every load is unconditional (rows that do not exist read a valid row and are zeroed by a select): branches around loads force
+    // s_waitcnt vmcnt(0) in the loop.
+    auto seg_get = [&](int sg, const double*& Ap, const double*& Bp, long& lda, long& ldb, int& K, bool& neg) {
+        if (pnseg > 0) { const GemmSeg* g = segs + sg; Ap = g->A; Bp = g->B; lda = g->lda; ldb = g->ldb; K = g->K; neg = g->neg != 0; }
+        else { Ap = pp->A; Bp = pp->B; lda = pp->lda; ldb = pp->ldb; K = pp->K; neg = false; }
+    };
+    int sg = 0, Kc = 0, k0 = 0;
+    const double *a0p = nullptr, *a1p = nullptr, *b0p = nullptr, *b1p = nullptr;
+    bool negc = false;
+    auto seg_enter = [&](int s_) -> bool {                  // first segment >= s_ with K > 0; sets the operand pointers
+        for (sg = s_; sg < nseg; ++sg) {
+            const double *Ap, *Bp;
+            long lda, ldb;
+            int Ks;
+            bool negs;
+            seg_get(sg, Ap, Bp, lda, ldb, Ks, negs);
+            if (Ks > 0) {
+                Kc = Ks; negc = negs;                       // (an empty segment leaves the state of the last real one alone)
+                a0p = Ap + (long)(m0 + r) * lda + 4 * q;
+                a1p = mv1 ? a0p + 16 * lda : a0p;
+                b0p = Bp + (long)(bz0 ? 0 : br0) * ldb + 4 * q;
+                b1p = Bp + (long)(bz1 ? 0 : br1) * ldb + 4 * q;
+                k0 = 0;
+                return true;
             }
+        }
+        return false;
+    };
+    bool more = seg_enter(0);
+    d4 na0 = zero, na1 = zero, nb0 = zero, nb1 = zero;
+    bool nneg = false;
+    if (more) { na0 = gld4(a0p); na1 = gld4(a1p); nb0 = gld4(b0p); nb1 = gld4(b1p); nneg = negc; }
+    while (more) {
+        const d4 a0 = nneg ? -na0 : na0, a1 = mv1 ? (nneg ? -na1 : na1) : zero, b0 = bz0 ? zero : nb0, b1 = bz1 ? zero : nb1;
+        k0 += 16;
+        if (k0 >= Kc) more = seg_enter(sg + 1);
+        {
+            const int ko = more ? k0 : Kc - 16;             // past the end: re-read the last step (unconditional loads, see above)
+            na0 = gld4(a0p + ko); na1 = gld4(a1p + ko); nb0 = gld4(b0p + ko); nb1 = gld4(b1p + ko); nneg = negc;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c00 = mfma16(a0[j], b0[j], c00);
+            c01 = mfma16(a0[j], b1[j], c01);
+            c10 = mfma16(a1[j], b0[j], c10);
+            c11 = mfma16(a1[j], b1[j], c11);
         }
     }
     // epilogue: accumulator element s of lane (r,q) is C[m + q + 4 s][n + r]
@@ -1938,9 +1962,11 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
 //  Outputs: mean (= -ycol) and var only; W is not written back.
 // ------------------------------------------------------------------------------------------------
 struct PredLevel {
-    const double* F;      // [node][nf][nf] factorised fronts of this level (Lt, Zt in place)
+    const double* F;      // [node] factorised fronts of this level (Lt, Zt in place): nf rows of ld doubles each, `stride` doubles per node
     const double* invF;   // [node][cwt][256]
     int nf;
+    int ld;               // = nf, or the block width when only the panel columns [Lt ; Zt] of the level's fronts are kept
+    long stride;          // = nf * ld
 };
 struct PredArgs {
     PredLevel lev[8];
@@ -1980,7 +2006,7 @@ struct PredArgs {
                 const int ms_ = (ms); \
                 const PredLevel ls = (lvl); \
                 const int slot_s = chain[ms_]; \
-                const double* Fs = ls.F + (long)slot_s * ls.nf * ls.nf; \
+                const double* Fs = ls.F + (long)slot_s * ls.stride; \
                 const double* invs = ls.invF + (long)slot_s * CWT * 256; \
                 const int total = (NTRI + CWT + (ms_ * CWT + 1) * CWT) * 128; \
 _Pragma("unroll") \
@@ -1995,12 +2021,12 @@ _Pragma("unroll") \
 _Pragma("unroll") \
                             for (int c = 1; c < CWT - 1; ++c) jb += (tile >= c * (c + 1) / 2) ? 1 : 0; \
                             const int kb = tile - jb * (jb - 1) / 2; \
-                            src = Fs + (long)(jb * 16 + row) * ls.nf + kb * 16 + c2; \
+                            src = Fs + (long)(jb * 16 + row) * ls.ld + kb * 16 + c2; \
                         } else if (tile < NTRI + CWT) { \
                             src = invs + (long)(tile - NTRI) * 256 + row * 16 + c2; \
                         } else { \
                             const int zt = tile - NTRI - CWT, a = zt / CWT, jb = zt % CWT; \
-                            src = Fs + (long)(CW + a * 16 + row) * ls.nf + jb * 16 + c2; \
+                            src = Fs + (long)(CW + a * 16 + row) * ls.ld + jb * 16 + c2; \
                         } \
                         pre[i] = *(const d2*)src; \
                     } \
@@ -2127,8 +2153,6 @@ _Pragma("unroll") \
         if (m < ar.nl) {
             const PredLevel lv = ar.lev[m];
             const int slot = chain[m];
-            const double* F = lv.F + (long)slot * lv.nf * lv.nf;
-            const double* inv = lv.invF + (long)slot * CWT * 256;
             const int nzt = (m * CWT + 1) * CWT;            // Zt tiles: ancestors' tiles + the y tile, CWT k-tiles each
             // ---- stage: Lt strictly-lower tiles, inverted diagonal blocks, Zt tiles [a][jb].  All of a
             // thread's loads are issued together, and the loads of level m-1 are issued BEFORE the
@@ -2297,8 +2321,8 @@ __global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const long slot = chain[h];
-        nfh[h] = ar.hi[h].nf;
-        Fh[h] = ar.hi[h].F + slot * nfh[h] * nfh[h];
+        nfh[h] = ar.hi[h].ld;
+        Fh[h] = ar.hi[h].F + slot * ar.hi[h].stride;
         invh[h] = ar.hi[h].invF + slot * 4 * 256;
     }
     d2 pre[8];

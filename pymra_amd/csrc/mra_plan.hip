@@ -158,10 +158,21 @@ static void build_static(mra_plan* pl) {
     pl->lev.clear();
     pl->lev.resize(L);
     pl->node_slot.assign(pl->n_nodes, -1);
+    {
+        // shape: every leaf on the last level, every other level non-leaf only (also decided again below for the fused paths)
+        bool ok = L >= 3;
+        for (int m = 0; m < L - 1 && ok; ++m)
+            for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1] && ok; ++i) if (pl->leaf[i]) ok = false;
+        for (long i = pl->level_ptr[L - 1]; i < pl->level_ptr[L] && ok; ++i) if (!pl->leaf[i]) ok = false;
+        // fronts of the leaves' parents too large for the register-resident k_parent_front: keep their panels only
+        pl->lowrank_parent = ok && pl->nf[L - 2] > 256 && !getenv("MRA_NO_LOWRANK_PARENT");
+    }
     for (int m = 0; m < L; ++m) {
         LevelData& lv = pl->lev[m];
         lv.cw = pl->cw[m]; lv.cwt = lv.cw / 16; lv.c0 = pl->coff[m]; lv.a0 = pl->asuf[m];
         lv.nf = pl->nf[m]; lv.na = pl->na[m];
+        lv.panel_only = pl->lowrank_parent && m == L - 2;
+        lv.ldf = lv.panel_only ? lv.cw : lv.nf;
         for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1]; ++i)
             if (!pl->leaf[i]) { pl->node_slot[i] = (int)lv.nodes.size(); lv.nodes.push_back((int)i); }
         const size_t nn = lv.nodes.size();
@@ -169,7 +180,7 @@ static void build_static(mra_plan* pl) {
         if (lv.cw == 0) throw MraError(MRA_ERR_INVALID, "level with non-leaf nodes has cw == 0");
         lv.Lp.alloc(nn * (size_t)lv.cw * lv.cw);
         lv.invP.alloc(nn * (size_t)lv.cwt * 256);
-        lv.F.alloc(nn * (size_t)lv.nf * lv.nf + 16);
+        lv.F.alloc(nn * (size_t)lv.nf * lv.ldf + 16);
         lv.invF.alloc(nn * (size_t)lv.cwt * 256);
     }
     // leaves
@@ -227,7 +238,7 @@ static void build_static(mra_plan* pl) {
             lv.max_rows = std::max(lv.max_rows, nr);
             const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
             double* Lp = lv.Lp.p + s * (size_t)lv.cw * lv.cw;
-            double* F = lv.F.p + s * (size_t)lv.nf * lv.nf;
+            double* F = lv.F.p + s * (size_t)lv.nf * lv.ldf;
             GemmProb g{};
             g.A = pl->W.p + r0 * pl->ldw + lv.a0; g.lda = pl->ldw;
             g.B = pl->W.p + lv.a0; g.ldb = pl->ldw; g.idxB = pl->knot_idx.p + pl->knot_idx_off[i];
@@ -241,24 +252,24 @@ static void build_static(mra_plan* pl) {
             pch[s] = PanelProb{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt, lv.cwt, i};
             lv.fl_pchol += Work(rkt * rkt * rkt / 3.0, (double)lv.cw * lv.cw * lv.cw / 3.0, 8.0 * 2 * lv.cw * lv.cw);
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
-            tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.cwt};
+            tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.ldf, lv.cwt};
             lv.fl_trsm += Work((double)nr * rkt * rkt, (double)nr * lv.cw * lv.cw, 8.0 * 2 * nr * lv.cw);
             t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
-            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.nf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
+            t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.ldf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
-            fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.nf, lv.nf / 16, lv.cwt, i};
+            fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.ldf, lv.nf / 16, lv.cwt, i};
             lv.fl_fchol += Work(rkt * rkt * rkt / 3.0 + nat * rkt * rkt, (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw,
                                 8.0 * (2.5 * lv.nf * (lv.nf + 1) / 2));      // four children's Schur blocks in (lower halves; fewer for ragged trees), the front out
             GemmProb sc{};
-            sc.A = F + (size_t)lv.cw * lv.nf; sc.lda = lv.nf; sc.B = sc.A; sc.ldb = lv.nf;
-            sc.C = F + (size_t)lv.cw * lv.nf + lv.cw; sc.ldc = lv.nf;
+            sc.A = F + (size_t)lv.cw * lv.ldf; sc.lda = lv.ldf; sc.B = sc.A; sc.ldb = lv.ldf;
+            sc.C = lv.panel_only ? nullptr : F + (size_t)lv.cw * lv.nf + lv.cw; sc.ldc = lv.nf;      // panel_only: no Schur block is ever formed
             sc.M = lv.na; sc.N = lv.na; sc.K = lv.cw; sc.lower = 1;
             schur[s] = sc;
             lv.fl_schur += Work(nat * nat * rkt, (double)lv.na * lv.na * lv.cw, 0.0);
             GemmProb u{};
             u.A = pl->W.p + r0 * pl->ldw + lv.c0; u.lda = pl->ldw;
-            u.B = F + (size_t)lv.cw * lv.nf; u.ldb = lv.nf;
+            u.B = F + (size_t)lv.cw * lv.ldf; u.ldb = lv.ldf;
             u.C = pl->W.p + r0 * pl->ldw + lv.a0; u.ldc = pl->ldw;
             u.M = (int)nr; u.N = lv.na; u.K = lv.cw; u.lower = 0;
             upd[s] = u;
@@ -274,7 +285,8 @@ static void build_static(mra_plan* pl) {
                 if (pl->leaf[ch]) { k.G = pl->Gt.p ? pl->Gt.p + pl->leaf_goff[pl->leaf_slot[ch]] : nullptr; k.ld = pl->na[m + 1]; }
                 else {
                     const LevelData& cl = pl->lev[m + 1];
-                    k.G = cl.F.p + (size_t)pl->node_slot[ch] * cl.nf * cl.nf + (size_t)cl.cw * cl.nf + cl.cw;
+                    // (children whose fronts are kept as panels have no Schur block: their parents are built by the signed SYRK)
+                    k.G = cl.panel_only ? nullptr : cl.F.p + (size_t)pl->node_slot[ch] * cl.nf * cl.nf + (size_t)cl.cw * cl.nf + cl.cw;
                     k.ld = cl.nf;
                 }
                 if (pl->na[m + 1] != lv.nf) throw MraError(MRA_ERR_INVALID, "front size mismatch");
@@ -288,6 +300,7 @@ static void build_static(mra_plan* pl) {
             const size_t full = (size_t)(nt * (nt + 1) / 2 + lv.cwt) * FT_SZ * sizeof(double);
             const size_t panel = (size_t)(lv.cwt * nt - lv.cwt * (lv.cwt - 1) / 2 + lv.cwt) * FT_SZ * sizeof(double);
             lv.front_mode = full <= 160 * 1024 ? 2 : (panel <= 160 * 1024 ? 1 : 0);
+            if (lv.panel_only) lv.front_mode = 0;
             lv.front_lds = lv.front_mode == 2 ? full : panel;
             lv.gFront.upload(fr);
         }
@@ -619,30 +632,84 @@ static void build_leaf(mra_plan* pl, const double* y) {
                 const int lt = pl->leaf_slot[pl->child_list[c]];
                 const int nop = pl->leaf_nop[lt];
                 double* ut = pl->panel.p + pl->leaf_poff[lt] + (size_t)nop * nop;
-                segs.push_back(GemmSeg{ut, ut, nop, nop, nop});
+                segs.push_back(GemmSeg{ut, ut, nop, nop, nop, 0});
             }
         }
         pl->parentSegs.upload(segs);
         for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx) {
             GemmProb g{};
-            g.C = lv.F.p + sidx * (size_t)lv.nf * lv.nf; g.ldc = lv.nf; g.M = lv.nf; g.N = lv.nf; g.lower = 1;
+            g.C = lv.panel_only ? nullptr : lv.F.p + sidx * (size_t)lv.nf * lv.nf; g.ldc = lv.nf; g.M = lv.nf; g.N = lv.nf; g.lower = 1;      // (not launched when panel_only)
             g.segs = pl->parentSegs.p + where[sidx].first; g.nseg = where[sidx].second; g.diag_one = lv.cw;
             if (g.nseg == 0) { g.nseg = 0; g.K = 0; g.A = g.B = pl->W.p; }
             ps[sidx] = g;
         }
         pl->gParentSyrk.upload(ps);
         pl->parent_syrk = true;
+        pl->fl_parent_panel = pl->fl_grand_syrk = Work();
+        if (pl->lowrank_parent && pl->NL >= 2) {
+            // panels of the leaves' parents: [F_oo + I ; F_ao] = U U_o^T over the children's Ut segments
+            std::vector<GemmProb> pp(lv.nodes.size());
+            for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx) {
+                GemmProb g{};
+                g.C = lv.F.p + sidx * (size_t)lv.nf * lv.ldf; g.ldc = lv.ldf; g.M = lv.nf; g.N = lv.cw; g.lower = 0;
+                g.segs = pl->parentSegs.p + where[sidx].first; g.nseg = where[sidx].second; g.diag_one = lv.cw;
+                if (g.nseg == 0) { g.K = 0; g.A = g.B = pl->W.p; }
+                pp[sidx] = g;
+                const int i = lv.nodes[sidx];
+                const double rkt = (double)(pl->knot_ptr[i + 1] - pl->knot_ptr[i]), nat = (double)pl->anc_rank[i] + 1.0;
+                double kobs = 0, kpad = 0;
+                for (int c = pl->child_ptr[i]; c < pl->child_ptr[i + 1]; ++c) { const int lt = pl->leaf_slot[pl->child_list[c]]; kobs += nobs[lt]; kpad += pl->leaf_nop[lt]; }
+                pl->fl_parent_panel += Work(2.0 * (rkt + nat) * rkt * kobs, 2.0 * lv.nf * lv.cw * kpad, 8.0 * (lv.nf * kpad + (double)lv.nf * lv.cw));
+            }
+            pl->gParentPanel.upload(pp);
+            // fronts of the grandparents: I + sum over grandchild leaves Ut[anc] Ut[anc]^T - sum over children Zt Zt^T
+            const LevelData& lg = pl->lev[pl->NL - 2];
+            std::vector<GemmSeg> gsegs;
+            std::vector<std::pair<size_t, int>> gwhere(lg.nodes.size());
+            for (size_t sidx = 0; sidx < lg.nodes.size(); ++sidx) {
+                const int i = lg.nodes[sidx];
+                const size_t first = gsegs.size();
+                const double rkt = (double)(pl->knot_ptr[i + 1] - pl->knot_ptr[i]), nft = rkt + (double)pl->anc_rank[i] + 1.0;
+                double kalg = 0, kpad = 0;
+                for (int c = pl->child_ptr[i]; c < pl->child_ptr[i + 1]; ++c) {
+                    const int ch = pl->child_list[c];                  // a parent of leaves
+                    for (int c2 = pl->child_ptr[ch]; c2 < pl->child_ptr[ch + 1]; ++c2) {
+                        const int lt = pl->leaf_slot[pl->child_list[c2]];
+                        const int nop = pl->leaf_nop[lt];
+                        if (!nop) continue;
+                        double* ut = pl->panel.p + pl->leaf_poff[lt] + (size_t)nop * nop + (size_t)lv.cw * nop;      // rows of the ancestors of `ch`
+                        gsegs.push_back(GemmSeg{ut, ut, nop, nop, nop, 0});
+                        kalg += nobs[lt]; kpad += nop;
+                    }
+                    double* zt = lv.F.p + (size_t)pl->node_slot[ch] * lv.nf * lv.ldf + (size_t)lv.cw * lv.ldf;
+                    gsegs.push_back(GemmSeg{zt, zt, lv.ldf, lv.ldf, lv.cw, 1});
+                    kalg += (double)(pl->knot_ptr[ch + 1] - pl->knot_ptr[ch]); kpad += lv.cw;
+                }
+                gwhere[sidx] = {first, (int)(gsegs.size() - first)};
+                pl->fl_grand_syrk += Work(nft * nft * kalg, (double)lg.nf * lg.nf * kpad, 8.0 * (lg.nf * kpad + 0.5 * lg.nf * (lg.nf + 1)));
+            }
+            pl->grandSegs.upload(gsegs);
+            std::vector<GemmProb> gp(lg.nodes.size());
+            for (size_t sidx = 0; sidx < lg.nodes.size(); ++sidx) {
+                GemmProb g{};
+                g.C = lg.F.p + sidx * (size_t)lg.nf * lg.nf; g.ldc = lg.nf; g.M = lg.nf; g.N = lg.nf; g.lower = 1;
+                g.segs = pl->grandSegs.p + gwhere[sidx].first; g.nseg = gwhere[sidx].second; g.diag_one = lg.cw;
+                if (g.nseg == 0) { g.K = 0; g.A = g.B = pl->W.p; }
+                gp[sidx] = g;
+            }
+            pl->gGrandSyrk.upload(gp);
+        }
         {
             std::vector<FrontProb> pf(lv.nodes.size());
             for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx)
-                pf[sidx] = FrontProb{lv.F.p + sidx * (size_t)lv.nf * lv.nf, lv.invF.p + sidx * (size_t)lv.cwt * 256, lv.nf, lv.cwt,
+                pf[sidx] = FrontProb{lv.F.p + sidx * (size_t)lv.nf * lv.ldf, lv.invF.p + sidx * (size_t)lv.cwt * 256, lv.nf, lv.cwt,
                                      lv.nodes[sidx], (int)where[sidx].first, where[sidx].second};
             pl->gParentFront.upload(pf);
             const long nt = lv.nf / 16, ntiles = nt * (nt + 1) / 2;
             const long npanel = lv.cwt * nt - lv.cwt * (lv.cwt - 1) / 2;
             pl->parent_front_lds = (size_t)(2 * lv.nf * PF_LD + (npanel + lv.cwt) * FT_SZ) * sizeof(double);
             pl->parent_front_nacc = ntiles <= 16 ? 2 : (ntiles <= 32 ? 4 : (ntiles <= 64 ? 8 : (ntiles <= 96 ? 12 : 0)));
-            if (pl->parent_front_lds > 160 * 1024) pl->parent_front_nacc = 0;
+            if (pl->parent_front_lds > 160 * 1024 || lv.panel_only) pl->parent_front_nacc = 0;
         }
     }
     pl->hLeafResid = gr; pl->leaf_nobs_host = nobs;
@@ -894,6 +961,7 @@ static void run_predict_hi(mra_plan* pl) {
     for (int h = 0; h < 4; ++h) {
         const int m = nlo + h;
         hi.hi[h].F = pl->lev[m].F.p; hi.hi[h].invF = pl->lev[m].invF.p; hi.hi[h].nf = pl->lev[m].nf;
+        hi.hi[h].ld = pl->lev[m].ldf; hi.hi[h].stride = (long)pl->lev[m].nf * pl->lev[m].ldf;
         hi.coff_hi[h] = pl->coff[m];
         fl_hi += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
     }
@@ -905,6 +973,7 @@ static void run_predict_hi(mra_plan* pl) {
     PredArgs lo{};
     for (int m = 0; m < nlo; ++m) {
         lo.lev[m].F = pl->lev[m].F.p; lo.lev[m].invF = pl->lev[m].invF.p; lo.lev[m].nf = pl->lev[m].nf;
+        lo.lev[m].ld = pl->lev[m].ldf; lo.lev[m].stride = (long)pl->lev[m].nf * pl->lev[m].ldf;
         lo.coff[m] = pl->coff[m];
         fl_lo += pl->lev[m].fl_trsm + pl->lev[m].fl_update;
     }
@@ -923,6 +992,7 @@ static void run_predict_fused(mra_plan* pl) {
     PredArgs ar{};
     for (int m = 0; m < pl->NL; ++m) {
         ar.lev[m].F = pl->lev[m].F.p; ar.lev[m].invF = pl->lev[m].invF.p; ar.lev[m].nf = pl->lev[m].nf;
+        ar.lev[m].ld = pl->lev[m].ldf; ar.lev[m].stride = (long)pl->lev[m].nf * pl->lev[m].ldf;
         ar.coff[m] = pl->coff[m];
     }
     ar.deep = ar.lev[pl->NL - 1];
@@ -1022,8 +1092,19 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                     }
                     continue;
                 }
+                if (lvp.panel_only) {
+                    // only the panel columns of these fronts exist: build them, factorise them, done with the level
+                    { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_parent_panel); launch_gemm<EPI_SET>(pl, pl->gParentPanel.p, lvp.nodes.size(), lvp.nf, lvp.cw, false, false); }
+                    { KTimer kt(pl, KF_FRONT_CHOL, pl->lev[m].fl_fchol.with_bytes(8.0 * 2 * lvp.nodes.size() * (double)lvp.nf * lvp.cw)); launch_panel(pl, pl->lev[m].gFrontChol.p, lvp.nodes.size()); }
+                    continue;
+                }
                 KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk);
                 launch_gemm<EPI_SET>(pl, pl->gParentSyrk.p, lvp.nodes.size(), lvp.nf, lvp.nf, false, true);
+            } else if (pl->direct_parent && m == pl->NL - 2 && pl->lev[pl->NL - 1].panel_only) {
+                if (is_red) throw MraError(MRA_ERR_STATE, "the reduce level cannot be the level above panel-only fronts");
+                const LevelData& lg = pl->lev[m];
+                KTimer kt(pl, KF_FRONT_SCHUR, pl->fl_grand_syrk);
+                launch_gemm<EPI_SET>(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, lg.nf, false, true);
             } else if (is_red) {
                 run_assemble_level(pl, m, false);
                 need_identity = true;
@@ -1712,7 +1793,11 @@ int mra_get_node_block(mra_plan* pl, int32_t node, int what, double* out, int64_
             const LevelData& lv = pl->lev[m];
             const size_t sl = (size_t)pl->node_slot[node];
             if (what == MRA_BLOCK_LPRIOR) { rows = cols = ld = lv.cw; src = lv.Lp.p + sl * (size_t)lv.cw * lv.cw; }
-            else { rows = cols = ld = lv.nf; src = lv.F.p + sl * (size_t)lv.nf * lv.nf; }
+            else {
+                if (lv.panel_only) throw MraError(MRA_ERR_STATE, "the fronts of this level are kept as their panel columns only (large fronts of the leaves' parents); "
+                                                                  "set MRA_NO_LOWRANK_PARENT=1 before creating the plan to get whole fronts");
+                rows = cols = ld = lv.nf; src = lv.F.p + sl * (size_t)lv.nf * lv.nf;
+            }
         } else if (what == MRA_BLOCK_LEAF) {
             if (!pl->leaf[node]) throw MraError(MRA_ERR_INVALID, "block exists for leaves only");
             const int t = pl->leaf_slot[node];
@@ -1919,6 +2004,8 @@ int mra_tree_free(mra_tree* t) { delete t; return MRA_OK; }
 int mra_plan_set_reduce_level(mra_plan* pl, int level) {
     if (!pl) return MRA_ERR_INVALID;
     if (level >= pl->n_levels) return fail(pl, MraError(MRA_ERR_INVALID, "reduce level out of range"));
+    if (pl->lowrank_parent && level >= pl->n_levels - 3)
+        return fail(pl, MraError(MRA_ERR_INVALID, "reduce level too deep: the fronts of the leaves' parents are kept as panels on this plan (set MRA_NO_LOWRANK_PARENT=1 before creating it)"));
     pl->reduce_level = level;
     return MRA_OK;
 }

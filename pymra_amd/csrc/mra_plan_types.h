@@ -149,6 +149,8 @@ struct DevVec {
 struct LevelData {
     std::vector<int> nodes;          // non-leaf nodes of this level
     int cw = 0, cwt = 0, c0 = 0, a0 = 0, nf = 0, na = 0;
+    int ldf = 0;                     // row stride of a front in F: nf, or cw when only the panel columns [Lt ; Zt] are kept (panel_only)
+    bool panel_only = false;
     long max_rows = 0;               // largest row range among the nodes
     DevVec<double> Lp, invP, F, invF;
     DevVec<GemmProb> gResid, gSchur, gUpdate;
@@ -235,6 +237,15 @@ struct mra_plan {
     int parent_front_nacc = 0;           // 0: not available (front too large for the register-resident SYRK)
     size_t parent_front_lds = 0;
     bool parent_syrk = false, direct_parent = false;
+    // Large fronts at the level of the leaves' parents (config 5: 528^2 per node, 36 GB in all) are never formed: F = I + U U^T with
+    // U = the children's Ut blocks side by side has rank <= sum(n_obs), so only its panel columns [F_oo ; F_ao] = U U_o^T (+ I) are
+    // built and factorised ([Lt ; Zt]), and the grandparents' fronts come straight from the leaves and the panels:
+    //     F_grand = I + sum_leaves Ut[anc] Ut[anc]^T - sum_parents Zt Zt^T        (Schur complement = F_aa - Zt Zt^T, MRANode.py:476-480)
+    // one signed, segmented SYRK instead of SYRK + Schur update + assembly of 528^2 blocks (95 GB of HBM traffic -> 37 GB).
+    bool lowrank_parent = false;
+    DevVec<GemmProb> gParentPanel, gGrandSyrk;
+    DevVec<GemmSeg> grandSegs;
+    Work fl_parent_panel, fl_grand_syrk;
     bool shape_regular = false;          // every leaf sits on the last level (all other levels hold non-leaf nodes only)
     std::vector<AsmChild> hKids;         // host copies: the leaves' Gt blocks are allocated only when something needs them
     std::vector<int> kid_leaf;
