@@ -127,7 +127,7 @@ def gp_sample_rff(c, l_true, seed=12345, n_feat=1024):
     return (np.sqrt(2.0 * c["sig"] / n_feat) * f).reshape(-1, 1), rng
 
 
-def mle_throughput(pl, c, kind, y_obs, l_true=0.2, max_evals=80):
+def mle_throughput(pl, c, kind, y_obs, l_true=0.1, max_evals=80):
     """End-to-end MLE of the range parameter on the resident plan, as README.md:96-104 / tests/test-param-est.py:81-123 do it with
     a new MRATree per call: Nelder-Mead from kappa_0 = 0.3 with xatol 1e-3 on -2 loglik = d + u (MRATree.getLikelihood), every
     objective call one likelihood-only device pass with new kernel parameters.  The data are a GP sample of the same kernel

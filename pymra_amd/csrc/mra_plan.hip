@@ -802,6 +802,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
                     if (small) nat_max = std::max(nat_max, q.nat);
                 }
             pl->gLeafSolve.upload(sp);
+            pl->gLeafUpdatePlain.upload(up);
             {
                 std::vector<long> lr0(nl);
                 std::vector<unsigned char> lup(nl);
