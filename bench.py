@@ -109,6 +109,31 @@ def cpu_baseline(topo, locs, y_obs, c, budget_nodes=85):
                                                                 if secs_1t else None)}}
 
 
+def cpu_baseline_whole_tree(topo, locs, y_obs, c):
+    """The WHOLE tree through the faithful restatement (oracle/mra_faithful.run_faithful, the reference's per-node recursion with
+    its own LAPACK calls and its per-node gc.collect(), MRANode.py:111): what BASELINE.md section 2 measured for the reference
+    itself (config 2: 89.6 s on the 8-core survey box).  Not an extrapolation from a subtree - minutes at c2, so on request only
+    (--whole-tree-cpu-baseline)."""
+    import pymra_amd.MRATools as mt
+    from oracle.mra_faithful import run_faithful
+    cov = (lambda a, b: mt.Matern32(a, b, l=c["l"], sig=c["sig"])) if c["kern"] == "m32" else \
+          (lambda a, b: mt.ExpCovFun(a, b, l=c["l"]))
+    tm = {}
+    t0 = time.perf_counter()
+    out = run_faithful(topo, locs, cov, y_obs, c["R"], do_gc=True, timers=tm)
+    secs = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        cores = max(pools) if pools else os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": topo.n_nodes / secs, "unit": "nodes/s", "cores": cores, "kind": "port",
+            "sample": "the whole tree (%d nodes), constructor-equivalent work incl. the per-node gc.collect(), NumPy/SciPy default BLAS "
+                      "threads" % topo.n_nodes, "seconds": secs, "nodes": int(topo.n_nodes), "likelihood": float(out["lik"]),
+            "timers": {k: float(v) for k, v in tm.items()}}
+
+
 def gp_sample_rff(c, l_true, seed=12345, n_feat=1024):
     """A Matern-3/2 Gaussian-process sample on the n x n grid of `c` by random Fourier features ("a smoother
     variant (random-Fourier-feature GP sample, same seed) may be added"): f(x) = sqrt(2 sig / D) sum_k cos(w_k . x + b_k) with w_k
@@ -169,6 +194,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--likelihood-only", action="store_true")
+    ap.add_argument("--whole-tree-cpu-baseline", action="store_true",
+                    help="time the faithful CPU restatement on the WHOLE tree of the configuration (about 90 s at c2, 30 min at c3) "
+                         "instead of the bounded subtree sample")
     ap.add_argument("--mle", action="store_true", help="add the end-to-end Nelder-Mead MLE block (always on for --config c5)")
     ap.add_argument("--allow-gloo-fallback", action="store_true",
                     help="with --exchange rccl: if RCCL cannot initialise, re-plan onto the host/gloo exchange instead of failing "
@@ -376,6 +404,10 @@ def main():
         out["mle"] = mle_throughput(pl, c, kind, y_obs)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(topo, locs, y_obs, c)
+        if args.whole_tree_cpu_baseline:
+            wt = cpu_baseline_whole_tree(topo, locs, y_obs, c)
+            wt["likelihood_rel_diff_vs_gpu"] = abs(wt["likelihood"] - (d + u)) / abs(d + u)
+            out["cpu_baseline_whole_tree"] = wt
         # end-to-end constructor wall-clock of the drop-in API (host tree build + H2D + device pass + D2H)
         from pymra_amd import MRATree
         np.random.seed(c["seed"]); make_inputs(c)            # RNG where the recipe leaves it
