@@ -2061,7 +2061,11 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
             for (int jb = 0; jb < CWT; ++jb) w[m][jb] = *(const d4*)(wrow + ar.coff[m] + jb * 16);
         }
     }
-    d4 yt = *(const d4*)(wrow + ar.ycol);
+    // The y block of W is 16 columns wide for the sake of the tile layout, but only its first column is data: it is carried as ONE
+    // number per row (this lane's share of it: the sum over the four lanes of a row is the value) and updated with a few FMAs on
+    // the row fragments the lane holds anyway, instead of as a thirteenth MFMA tile (7.7 % of the update's and ~8 % of every
+    // level's matrix instructions at C3, and one LDS fragment per step)
+    double yv = (q == 0) ? ar.W[myrow * ar.ldw + ar.ycol] : 0.0;
     double ssq = 0.0;
     MRA_PSTAMP(0);
     MRA_PSTAMP_WALL(13);
@@ -2075,7 +2079,7 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
             // Tt fragments of the row tile, one 16 x 8 chunk at a time (lane (r, q) holds k = 2q, 2q+1 of the chunk), fetched
             // one chunk ahead: holding all of Tt would cost 32 registers and the third wave per SIMD with them
             const double* tt = ut + (long)ar.na * nop + (myrow - ar.leaf_row0[lf]) * nop + 2 * q;
-            yt = zero;                                       // the y block takes C_in = 0 (the column still holds y itself)
+            yv = 0.0;                                        // the y block takes C_in = 0 (the column still holds y itself)
             const int nat = ar.nl * CWT + 1;
             const int nch = nat * 64;                        // 16-byte pieces of a (nat*16) x 8 chunk of Ut, 4 per row
             constexpr int NSTU = ((NLMAX * CWT + 1) * 64 + NTH - 1) / NTH;
@@ -2101,6 +2105,7 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
                     const double x0 = -xc[0], x1 = -xc[1]; \
                     const double* cb = cur + prow * 8 + 2 * q; \
                     d2 bq[2][CWT]; \
+                    const d2 uy = *(const d2*)(cur + (ar.nl * CWT) * 128 + 2 * q);      /* row 0 of the y tile: Ut_y[2q], Ut_y[2q+1] */ \
 _Pragma("unroll") \
                     for (int kt = 0; kt < CWT; ++kt) bq[0][kt] = *(const d2*)(cb + ((ar.nl - 1) * CWT + kt) * 128); \
 _Pragma("unroll") \
@@ -2109,8 +2114,6 @@ _Pragma("unroll") \
                             if (k + 1 < ar.nl) { \
 _Pragma("unroll") \
                                 for (int kt = 0; kt < CWT; ++kt) bq[(k + 1) & 1][kt] = *(const d2*)(cb + ((ar.nl - 2 - k) * CWT + kt) * 128); \
-                            } else { \
-                                bq[(k + 1) & 1][0] = *(const d2*)(cb + (ar.nl * CWT) * 128); \
                             } \
 _Pragma("unroll") \
                             for (int kt = 0; kt < CWT; ++kt) { \
@@ -2118,10 +2121,7 @@ _Pragma("unroll") \
                                 w[k][kt] = mfma16(bq[k & 1][kt][1], x1, w[k][kt]); \
                             } \
                             __builtin_amdgcn_sched_barrier(0); \
-                            if (k + 1 == ar.nl) { \
-                                yt = mfma16(bq[(k + 1) & 1][0][0], x0, yt); \
-                                yt = mfma16(bq[(k + 1) & 1][0][1], x1, yt); \
-                            } \
+                            if (k + 1 == ar.nl) yv = __builtin_fma(uy[0], x0, __builtin_fma(uy[1], x1, yv)); \
                         } \
                     } \
                 } \
@@ -2214,15 +2214,13 @@ _Pragma("unroll") \
                     }
                 }
                 {
-                    const int a = m * CWT;                   // the y tile follows the ancestors
-                    d4 acc = zero;
+                    const int a = m * CWT;                   // the y tile follows the ancestors: its first row is Zt's y row
 #pragma unroll
                     for (int jb = 0; jb < CWT; ++jb) {
-                        const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + prow * 16 + 4 * q);
+                        const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + 4 * q);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc = mfma16(z[j], x[jb][j], acc);
+                        for (int j = 0; j < 4; ++j) yv = __builtin_fma(-z[j], x[jb][j], yv);
                     }
-                    yt -= acc;
                 }
             }
             if (m < 5) MRA_PSTAMP(4 + 2 * m);
@@ -2233,10 +2231,12 @@ _Pragma("unroll") \
     if (!active) return;
     ssq += __shfl_xor(ssq, 16, 64);
     ssq += __shfl_xor(ssq, 32, 64);
+    yv += __shfl_xor(yv, 16, 64);
+    yv += __shfl_xor(yv, 32, 64);
     if (q == 0) {
         const double v0 = ar.var[myrow];
         ar.var[myrow] = (v0 > 0.0 ? v0 : 0.0) + ssq;
-        ar.mean[myrow] = -yt[0];
+        ar.mean[myrow] = -yv;
     }
 }
 
