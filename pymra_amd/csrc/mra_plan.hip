@@ -165,7 +165,7 @@ static void build_static(mra_plan* pl) {
             for (long i = pl->level_ptr[m]; i < pl->level_ptr[m + 1] && ok; ++i) if (pl->leaf[i]) ok = false;
         for (long i = pl->level_ptr[L - 1]; i < pl->level_ptr[L] && ok; ++i) if (!pl->leaf[i]) ok = false;
         // fronts of the leaves' parents too large for the register-resident k_parent_front: keep their panels only
-        pl->lowrank_parent = ok && pl->nf[L - 2] > 256 && !getenv("MRA_NO_LOWRANK_PARENT");
+        pl->lowrank_parent = ok && pl->nf[L - 2] > 256 && pl->cw[L - 2] <= 7 * 16 && !getenv("MRA_NO_LOWRANK_PARENT");
     }
     for (int m = 0; m < L; ++m) {
         LevelData& lv = pl->lev[m];
@@ -647,14 +647,25 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->parent_syrk = true;
         pl->fl_parent_panel = pl->fl_grand_syrk = Work();
         if (pl->lowrank_parent && pl->NL >= 2) {
-            // panels of the leaves' parents: [F_oo + I ; F_ao] = U U_o^T over the children's Ut segments
+            // panels of the leaves' parents, in three launches: the own block F_oo = I + U_o U_o^T with its Cholesky (k_parent_front on
+            // a front of cw rows: everything in registers / LDS), the rows below F_ao = U_a U_o^T (one GEMM over the children's Ut
+            // segments, A = their ancestor rows, B = their own-block rows), and the row solve Zt = F_ao Lt^-T in place
+            std::vector<GemmSeg> segs_ao;
+            for (const GemmSeg& sg : segs) segs_ao.push_back(GemmSeg{sg.A + (size_t)lv.cw * sg.lda, sg.B, sg.lda, sg.ldb, sg.K, 0});
+            pl->parentSegsAo.upload(segs_ao);
             std::vector<GemmProb> pp(lv.nodes.size());
+            std::vector<FrontProb> pown(lv.nodes.size());
+            std::vector<Trsm2Prob> pzt(lv.nodes.size());
             for (size_t sidx = 0; sidx < lv.nodes.size(); ++sidx) {
+                double* panel_s = lv.F.p + sidx * (size_t)lv.nf * lv.ldf;
+                double* inv_s = lv.invF.p + sidx * (size_t)lv.cwt * 256;
                 GemmProb g{};
-                g.C = lv.F.p + sidx * (size_t)lv.nf * lv.ldf; g.ldc = lv.ldf; g.M = lv.nf; g.N = lv.cw; g.lower = 0;
-                g.segs = pl->parentSegs.p + where[sidx].first; g.nseg = where[sidx].second; g.diag_one = lv.cw;
+                g.C = panel_s + (size_t)lv.cw * lv.ldf; g.ldc = lv.ldf; g.M = lv.na; g.N = lv.cw; g.lower = 0;
+                g.segs = pl->parentSegsAo.p + where[sidx].first; g.nseg = where[sidx].second; g.diag_one = 0;
                 if (g.nseg == 0) { g.K = 0; g.A = g.B = pl->W.p; }
                 pp[sidx] = g;
+                pown[sidx] = FrontProb{panel_s, inv_s, lv.cw, lv.cwt, lv.nodes[sidx], (int)where[sidx].first, where[sidx].second};
+                pzt[sidx] = Trsm2Prob{panel_s, inv_s, panel_s + (size_t)lv.cw * lv.ldf, nullptr, lv.ldf, lv.ldf, lv.cwt, lv.na / 16, 0, 1.0, nullptr, nullptr, 0, 0};
                 const int i = lv.nodes[sidx];
                 const double rkt = (double)(pl->knot_ptr[i + 1] - pl->knot_ptr[i]), nat = (double)pl->anc_rank[i] + 1.0;
                 double kobs = 0, kpad = 0;
@@ -662,6 +673,12 @@ static void build_leaf(mra_plan* pl, const double* y) {
                 pl->fl_parent_panel += Work(2.0 * (rkt + nat) * rkt * kobs, 2.0 * lv.nf * lv.cw * kpad, 8.0 * (lv.nf * kpad + (double)lv.nf * lv.cw));
             }
             pl->gParentPanel.upload(pp);
+            pl->gParentOwn.upload(pown);
+            pl->gParentZt.upload(pzt);
+            {
+                const long nt = lv.cwt, npanel = lv.cwt * nt - lv.cwt * (lv.cwt - 1) / 2;
+                pl->parent_own_lds = (size_t)(2 * lv.cw * PF_LD + (npanel + lv.cwt) * FT_SZ) * sizeof(double);
+            }
             // fronts of the grandparents: I + sum over grandchild leaves Ut[anc] Ut[anc]^T - sum over children Zt Zt^T
             const LevelData& lg = pl->lev[pl->NL - 2];
             std::vector<GemmSeg> gsegs;
@@ -1095,8 +1112,19 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 }
                 if (lvp.panel_only) {
                     // only the panel columns of these fronts exist: build them, factorise them, done with the level
-                    { KTimer kt(pl, KF_LEAF_SYRK, pl->fl_parent_panel); launch_gemm<EPI_SET>(pl, pl->gParentPanel.p, lvp.nodes.size(), lvp.nf, lvp.cw, false, false); }
-                    { KTimer kt(pl, KF_FRONT_CHOL, pl->lev[m].fl_fchol.with_bytes(8.0 * 2 * lvp.nodes.size() * (double)lvp.nf * lvp.cw)); launch_panel(pl, pl->lev[m].gFrontChol.p, lvp.nodes.size()); }
+                    const size_t nnp = lvp.nodes.size();
+                    ensure_big_lds(pl, {(const void*)k_parent_front<2>, (const void*)k_parent_front<4>});
+                    {
+                        KTimer kt(pl, KF_LEAF_SYRK, pl->fl_parent_panel);
+                        if (lvp.cwt <= 4) hipLaunchKernelGGL(k_parent_front<2>, dim3((unsigned)nnp), dim3(512), pl->parent_own_lds, pl->stream, pl->gParentOwn.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p);
+                        else hipLaunchKernelGGL(k_parent_front<4>, dim3((unsigned)nnp), dim3(512), pl->parent_own_lds, pl->stream, pl->gParentOwn.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p);
+                        launch_gemm<EPI_SET>(pl, pl->gParentPanel.p, nnp, lvp.na, lvp.cw, false, false);
+                    }
+                    {
+                        KTimer kt(pl, KF_FRONT_CHOL, pl->lev[m].fl_fchol.with_bytes(8.0 * 2 * nnp * (double)lvp.na * lvp.cw));
+                        if (!launch_trsm2(pl, pl->gParentZt.p, nnp, lvp.cwt, lvp.na / 16, lvp.na / 16))
+                            throw MraError(MRA_ERR_STATE, "panel row solve: block too wide for the LDS row solve");
+                    }
                     continue;
                 }
                 KTimer kt(pl, KF_LEAF_SYRK, pl->fl_leaf_syrk);
@@ -1298,7 +1326,9 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     // ---- 2. leaves
     const size_t nl = pl->leaf_nodes.size();
     if (nl) {
-        const bool c_only = !pred && fused && pl->gemm_lds && pl->leaf_max_nop / 16 <= 12;
+        // likelihood-only passes never need V[S,o]: just C = v_m(o,o) + R I from a small gathered product (the row solve gathers Ut itself
+        // on the level-by-level path, the row cascade has scattered it on the fused one)
+        const bool c_only = !pred && !pl->host_cov && pl->gemm_lds && pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0;
         {
             KTimer kt(pl, KF_LEAF_RESID, c_only ? pl->fl_leaf_c_only : pl->fl_leaf_resid);
             if (pl->host_cov) {

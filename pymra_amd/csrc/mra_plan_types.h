@@ -244,7 +244,10 @@ struct mra_plan {
     // one signed, segmented SYRK instead of SYRK + Schur update + assembly of 528^2 blocks (95 GB of HBM traffic -> 37 GB).
     bool lowrank_parent = false;
     DevVec<GemmProb> gParentPanel, gGrandSyrk;
-    DevVec<GemmSeg> grandSegs;
+    DevVec<GemmSeg> grandSegs, parentSegsAo;
+    DevVec<FrontProb> gParentOwn;         // k_parent_front on the own (cw x cw) block alone: F_oo = I + U_o U_o^T -> Lt, inverted diagonal blocks, log det
+    DevVec<Trsm2Prob> gParentZt;          // Zt = F_ao Lt^-T, row solve of the panel's lower part in place
+    size_t parent_own_lds = 0;
     Work fl_parent_panel, fl_grand_syrk;
     bool shape_regular = false;          // every leaf sits on the last level (all other levels hold non-leaf nodes only)
     std::vector<AsmChild> hKids;         // host copies: the leaves' Gt blocks are allocated only when something needs them

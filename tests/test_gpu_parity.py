@@ -341,6 +341,9 @@ def test_level_by_level_kernels_equal_fused_kernels(hip):
         m2, v2 = pl.predict()
         assert abs(d + u - lik) <= 1e-12 * abs(lik)
         assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10
+        pl.run(True, False)                       # likelihood only on the level-by-level path: C from the small gathered product
+        d, u = pl.likelihood()
+        assert abs(d + u - lik) <= 1e-12 * abs(lik)
         pl.close()
 
 
