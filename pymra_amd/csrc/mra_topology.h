@@ -228,7 +228,8 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     if ((int)inv.size() < M) inv.resize(M);
     for (int m = 1; m < M; ++m) inv[m].resize(N);
     leaf_of.resize(N);
-    const int n_thr = (int)std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    int n_thr = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("MRA_HOST_THREADS")) n_thr = std::max(1, atoi(e));
     int failed = 0;
     for (int m = 0; m < M; ++m) {
         const std::vector<int32_t>& ord = orders[m];
