@@ -33,7 +33,8 @@ ALLOWED = [
     # dominant kernel at three workgroups per CU (168 registers): the staging registers of the NEXT level's operands are parked
     # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
     # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
-    (r"k_predict_cascade<2, 6, 4, (true|false), 3>", 80, "level-operand staging parked across the level barrier"),
+    (r"k_predict_cascade<2, 6, 4, (true|false), 3>", 96, "level-operand staging parked across the level barrier"),
+    (r"k_predict_cascade<2, 8, 8, (true|false), 1>", 72, "eight row tiles per workgroup at 7-8 levels: not launched (cascade_wpw = 4)"),
     # the diagonal-block routine (chol16_inv, ~100 registers) runs beside 96 accumulator registers; the spills sit around it,
     # once per workgroup, outside the K loop
     (r"k_parent_front<12>", 40, "around chol16_inv, outside the K loop"),
