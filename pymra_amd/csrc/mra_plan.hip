@@ -821,6 +821,22 @@ static void build_leaf(mra_plan* pl, const double* y) {
             pl->gLeafSolve.upload(sp);
             pl->gLeafUpdatePlain.upload(up);
             {
+                std::vector<LeafSolveProb> half;
+                for (size_t k = 0; k < pl->n_trsm_small && k < sp.size(); ++k) {
+                    const LeafSolveProb& q = sp[k];
+                    const int h0 = (q.nrt + 1) / 2;
+                    for (int part = 0; part < 2; ++part) {
+                        LeafSolveProb h = q;
+                        const int t0 = part ? h0 : 0, t1 = part ? q.nrt : h0;
+                        if (t1 <= t0) continue;
+                        h.V = q.V + (size_t)t0 * 16 * q.ldx; h.Wr = q.Wr + (size_t)t0 * 16 * q.ldw; h.var = q.var + (size_t)t0 * 16; h.nrt = t1 - t0;
+                        half.push_back(h);
+                    }
+                }
+                pl->n_leaf_solve_half = half.size();
+                pl->gLeafSolveHalf.upload(half);
+            }
+            {
                 std::vector<long> lr0(nl);
                 std::vector<unsigned char> lup(nl);
                 for (size_t t = 0; t < nl; ++t) { lr0[t] = pl->row0[pl->leaf_nodes[t]]; lup[t] = tf[t].nt <= 8 ? 1 : 0; }
@@ -1436,7 +1452,10 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 ensure_big_lds(pl, {(const void*)k_leaf_solve_update<8, 13, true>});
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
                 const size_t ns = pl->n_trsm_small;
-                hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p);
+                if (pl->leaf_solve_split == 2 && pl->n_leaf_solve_half)
+                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)pl->n_leaf_solve_half), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolveHalf.p);
+                else
+                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p);
                 if (nl > ns) launch_gemm<EPI_SUB>(pl, pl->gLeafUpdatePlain.p + ns, nl - ns, pl->leaf_max_rows, pl->leaf_max_na);
             } else {
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
@@ -1861,6 +1880,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 6) { pl->use_leaf_gemm = value != 0; pl->leaf_gemm_update = value == 2; return MRA_OK; }
     if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
     if (option == 8) { pl->use_pred_update = value != 0; return MRA_OK; }
+    if (option == 10) { pl->leaf_solve_split = value == 2 ? 2 : 1; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
         // wide leaf-residual shape); bits 1, 2, 4 (no Ut scatter / no W stores / constant instead of the kernel) give WRONG results
@@ -1887,6 +1907,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 6: *value = pl->use_leaf_gemm ? (pl->leaf_gemm_update ? 2 : 1) : 0; break;
         case 7: *value = pl->leaf_solve_mode; break;
         case 8: *value = pl->use_pred_update; break;
+        case 10: *value = pl->leaf_solve_split; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
     }

@@ -222,6 +222,9 @@ struct mra_plan {
     std::vector<long> bigM[2], bigN[2];
     DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
     DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
+    DevVec<LeafSolveProb> gLeafSolveHalf; // the small leaves again, two workgroups each (row tiles split in two): shorter workgroups on the
+    size_t n_leaf_solve_half = 0;         // side stream free their CUs sooner for the high-priority front chain (MRA_OPT_LEAF_SOLVE_SPLIT)
+    int leaf_solve_split = 2;             // measured on an eighth of C3: 1.086 -> 1.066 ms
     DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
     bool use_leaf_solve = true, leaf_solve_ok = false;
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade

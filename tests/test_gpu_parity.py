@@ -354,8 +354,8 @@ def test_single_launch_chains_equal_per_level_launches(hip, name):
     the launch sequences / kernels they replace."""
     cs = K.load_case(name)
     pl, lik, mean, var = run_hip(hip, cs)
-    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (8, 0), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0)):
-        pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1); pl.set_option(7, 2); pl.set_option(8, 1)
+    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (7, 1, 10, 1), (8, 0), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0)):
+        pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1); pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(10, 2)
         for o, v in zip(opts[::2], opts[1::2]):
             pl.set_option(o, v)
         pl.run(True, True)
