@@ -2447,13 +2447,27 @@ _Pragma("unroll") \
 // ------------------------------------------------------------------------------------------------
 // W[:, Ka] = y (0 where missing), W[:, Ka+1 .. Ka+15] = 0
 #ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
-__global__ void k_init_yblock(double* __restrict__ W, long ldw, int Ka, const double* __restrict__ y, long P) {
+// var (optional): the prior variance C(x,x) of every row, from which the level-by-level row solves then subtract |W^m[x]|^2 level by
+// level and the leaf solve |Tt[x]|^2 (instead of a separate pass over all of W at the end: k_leaf_moments)
+__global__ void k_init_yblock(double* __restrict__ W, long ldw, int Ka, const double* __restrict__ y, long P,
+                              double* __restrict__ var, double cov0, const double* __restrict__ diag_host) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * MRA_YB) return;
     long p = i / MRA_YB; int c = (int)(i % MRA_YB);
     double v = 0.0;
-    if (c == 0) { double yy = y[p]; v = isfinite(yy) ? yy : 0.0; }
+    if (c == 0) {
+        double yy = y[p]; v = isfinite(yy) ? yy : 0.0;
+        if (var) var[p] = diag_host ? diag_host[p] : cov0;
+    }
     W[p * ldw + Ka + c] = v;
+}
+// what is left of k_leaf_moments when the row solves have accumulated the variance: clamp at 0, reset the y column of the leaves' rows
+__global__ void k_leaf_finish_var(const int* __restrict__ row_leaf, double* __restrict__ W, long ldw, int Ka, double* __restrict__ var, long P) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || row_leaf[p] < 0) return;
+    const double v = var[p];
+    var[p] = v > 0.0 ? v : 0.0;
+    W[p * ldw + Ka] = 0.0;
 }
 #endif
 

@@ -254,7 +254,8 @@ static void build_static(mra_plan* pl) {
             tpr[s] = TrsmNode{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, lv.cw, lv.cwt};
             tpo[s] = TrsmNode{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.ldf, lv.cwt};
             lv.fl_trsm += Work((double)nr * rkt * rkt, (double)nr * lv.cw * lv.cw, 8.0 * 2 * nr * lv.cw);
-            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, nullptr, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
+            // (var -= |W^m[x]|^2 rides on the row solve: the prior variance of the level-by-level path, see k_init_yblock)
+            t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, -1.0, nullptr, nullptr, 0, 0};
             t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.ldf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
             for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
@@ -1309,8 +1310,14 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     if (!(pl->regular && pl->use_fused && !pl->host_cov)) {        // the fused prior cascade writes the y block itself
         KTimer kt(pl, KF_MISC, 0);
         const long n = pl->P * MRA_YB;
+        // every level's row solve takes the LDS path (block width <= 192) and the leaves' solve subtracts |Tt|^2: the variance is
+        // accumulated on the way instead of by a pass over all of W at the end
+        bool acc_var = pl->leaf_max_nop / 16 <= 12;
+        for (int m = 0; m < pl->n_levels; ++m) if (!pl->lev[m].nodes.empty() && pl->lev[m].cwt > 12) acc_var = false;
+        pl->var_accumulated = acc_var;
         hipLaunchKernelGGL(k_init_yblock, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pl->stream, pl->W.p,
-                           (long)pl->ldw, pl->Ka, pl->y.p, pl->P);
+                           (long)pl->ldw, pl->Ka, pl->y.p, pl->P, acc_var ? pl->var.p : (double*)nullptr, pl->host_cov ? 0.0 : kernel_cov0(pl),
+                           pl->host_cov ? pl->covdiag.p : (const double*)nullptr);
     }
     // ---- 1. prior, top-down
     const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
@@ -1421,7 +1428,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 HIP_TRY(hipStreamWaitEvent(pl->stream2, pl->ev_fork, 0));
                 pl->stream = pl->stream2;                    // the launch helpers below use pl->stream
             }
-            if (!fused || pl->leaf_max_nop / 16 > 12) {
+            if (!fused && pl->var_accumulated) {
+                KTimer kt(pl, KF_MISC, 0);
+                hipLaunchKernelGGL(k_leaf_finish_var, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream, pl->row_leaf.p, pl->W.p,
+                                   (long)pl->ldw, pl->Ka, pl->var.p, pl->P);
+            } else if (!fused || pl->leaf_max_nop / 16 > 12) {
                 KTimer kt(pl, KF_MISC, 0);
                 double cov0 = 0.0;
                 if (!pl->host_cov) {

@@ -266,6 +266,7 @@ struct mra_plan {
     // fused ("regular tree") path
     // deep trees with 64-wide blocks (5 - 8 non-leaf levels of four tiles: BASELINE config 5): too many tiles per row for the one-kernel
     // cascades; the predictive pass runs as k_predict_hi (four deepest levels) + k_predict_cascade (coarse levels)
+    bool var_accumulated = false;       // level-by-level path: the row solves have accumulated the prior / leaf variance (no k_leaf_moments pass)
     bool regular_hi = false;
     DevVec<long> hi_wg0_8;
     DevVec<int> hi_wgn_8;
