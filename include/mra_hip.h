@@ -182,6 +182,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_PRED_UPDATE    8   /* 1 (default): the leaf update is applied inside the predictive cascade (W is not rewritten); 0: separate product */
 #define MRA_OPT_LEAF_SOLVE_SPLIT 10 /* 2 (default): the fused row solve + update runs two workgroups per leaf (half the row tiles each), so that
                                       the side stream frees CUs sooner for the front chain; 1: one workgroup per leaf */
+#define MRA_OPT_CHOL_TILES     11  /* leaf Cholesky by one workgroup per matrix with the tiles in registers (k_chol_tiles): 1 (default) when a CU sees
+                                      at most two leaves of at most 160 observations (sharded runs), 2 always, 0 never (one wave per matrix, k_chol_wave) */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 /* current value of an option (so that a caller can change one temporarily and put it back) */

@@ -1044,6 +1044,158 @@ __global__ __launch_bounds__(256, 3) void k_chol_wave(const PanelProb* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+//  The same factorisation with one WORKGROUP per matrix and the matrix in REGISTERS.  k_chol_wave is one wave per matrix walking
+//  a chain of global round trips (L2-hot, but 90 us for 112 x 112 however few matrices there are - a fixed cost of every shard).
+//  A 16 x 16 tile is 4 doubles per lane: the strictly-lower tiles are dealt to the NW - 1 worker waves (tile t to worker
+//  t mod (NW - 1), NSLOT tiles each, never moved), the diagonal tiles live in LDS, and wave 0 does nothing but factorise + invert
+//  diagonal blocks (the 3.3 us atom) - the NEXT one while the workers apply the rest of the trailing update (right-looking):
+//      A   workers: column jb below the diagonal, X = T L_jj^{-T}, to LDS (exchange buffer, by row tile) and to global memory
+//      B   wave 0:  tile (jb+1, jb+1) -= X X^T, factorise + invert it;   workers: their tiles (ib, jc) -= X_ib X_jc^T, jc > jb,
+//                   and the later diagonal tiles
+//  Two barriers per column, about 4.5 us per column.  Wave 0 and the workers run separate loops (same barrier count), so that the
+//  register allocation is the larger of the two working sets, not their sum.  LDS: 2 NT + 1 tiles of 2 KB.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, NT <= 8 ? 3 : 2) void k_chol_tiles(const PanelProb* __restrict__ probs, double* __restrict__ dnode,
+                                                                      int* __restrict__ err) {
+    constexpr int NWK = NW - 1;
+    constexpr int NOFF = NT * (NT - 1) / 2;
+    constexpr int NSLOT = (NOFF + NWK - 1) / NWK;
+    constexpr int NTH = NW * 64;
+    __shared__ __attribute__((aligned(16))) double sdiag[NT * 256];
+    __shared__ __attribute__((aligned(16))) double sx[NT * 256];
+    __shared__ __attribute__((aligned(16))) double finv[256];
+    const PanelProb pb = probs[blockIdx.x];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int prow = pi16(r);
+    const int nt = pb.ne;
+    const d4 zero = {0, 0, 0, 0};
+    if (nt == 0) {                                   // a leaf without observations
+        if (threadIdx.x == 0) dnode[pb.node] = 0.0;
+        return;
+    }
+    // ---- diagonal tiles into LDS (16-byte pieces, all loads of a thread in flight before its first write)
+    {
+        constexpr int PD = (NT * 128 + NTH - 1) / NTH;
+        const int total = nt * 128;
+        d2 v[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            int e = (int)threadIdx.x + i * NTH;
+            e = e < total ? e : total - 1;
+            const int tile = e >> 7, row = (e >> 3) & 15, c2 = (e & 7) << 1;
+            v[i] = gld2(pb.P + (long)(tile * 16 + row) * pb.ld + tile * 16 + c2);
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            const int e = (int)threadIdx.x + i * NTH;
+            if (e < total) *(d2*)(sdiag + (long)e * 2) = v[i];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double logacc = 0.0;
+        bool bad = false;
+        // factorise + invert diagonal tile jd: factor to global memory, inverse into finv and to global memory
+        auto factor = [&](int jd) {
+            double a[16], m[16];
+            const double* dt = sdiag + jd * 256;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * 16 + k] : 0.0;
+            logacc += chol16_inv(a, m, r, bad, nullptr);
+            if (lane < 16) {
+                double* dp = pb.P + (long)(jd * 16 + lane) * pb.ld + jd * 16;
+                double* ip2 = pb.invd + (long)jd * 256;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) {
+                    gst2(dp + k, d2{a[k], a[k + 1]});
+                    *(d2*)(finv + lane * 16 + k) = d2{m[k], m[k + 1]};
+                    gst2(ip2 + lane * 16 + k, d2{m[k], m[k + 1]});
+                }
+            }
+        };
+        factor(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int jb = 0; jb < nt - 1; ++jb) {
+            __syncthreads();                                   // column jb is in sx
+            const int j1 = jb + 1;
+            const d4 a = *(const d4*)(sx + j1 * 256 + prow * 16 + 4 * q);
+            const d4 b = *(const d4*)(sx + j1 * 256 + r * 16 + 4 * q);
+            d4 u0 = mfma16(a[0], b[0], zero), u1 = mfma16(a[1], b[1], zero);
+            u0 = mfma16(a[2], b[2], u0);
+            u1 = mfma16(a[3], b[3], u1);
+            d4* tp = (d4*)(sdiag + j1 * 256 + r * 16 + 4 * q);
+            *tp = *tp - (u0 + u1);
+            lds_wave_sync();
+            factor(j1);
+            __syncthreads();
+        }
+        if (lane == 0) {
+            dnode[pb.node] = 2.0 * logacc;
+            if (bad) atomicMax(err, pb.node + 1);
+        }
+    } else {
+        const int w = wave - 1;
+        d4 T[NSLOT];
+        int tib[NSLOT], tjc[NSLOT];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int t = s * NWK + w;
+            int ib = 1;
+            while ((ib + 1) * ib / 2 <= t) ++ib;
+            tib[s] = (t < NOFF && ib < nt) ? ib : 0;            // 0: no such tile in this matrix
+            tjc[s] = t - ib * (ib - 1) / 2;
+            T[s] = zero;
+            if (tib[s]) T[s] = gld4(pb.P + (long)(tib[s] * 16 + r) * pb.ld + tjc[s] * 16 + 4 * q);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int jb = 0; jb < nt - 1; ++jb) {
+            // ---- A
+            {
+                const d4 ia = *(const d4*)(finv + prow * 16 + 4 * q);
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s) {
+                    if (tib[s] && tjc[s] == jb) {
+                        d4 x0 = mfma16(ia[0], T[s][0], zero), x1 = mfma16(ia[1], T[s][1], zero);
+                        x0 = mfma16(ia[2], T[s][2], x0);
+                        x1 = mfma16(ia[3], T[s][3], x1);
+                        const d4 x = x0 + x1;
+                        *(d4*)(sx + tib[s] * 256 + r * 16 + 4 * q) = x;
+                        gst4(pb.P + (long)(tib[s] * 16 + r) * pb.ld + jb * 16 + 4 * q, x);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- B
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if (tib[s] && tjc[s] > jb) {
+                    const d4 a = *(const d4*)(sx + tjc[s] * 256 + prow * 16 + 4 * q);
+                    const d4 b = *(const d4*)(sx + tib[s] * 256 + r * 16 + 4 * q);
+                    d4 u = mfma16(-a[1], b[1], zero);
+                    T[s] = mfma16(-a[0], b[0], T[s]);
+                    u = mfma16(-a[3], b[3], u);
+                    T[s] = mfma16(-a[2], b[2], T[s]);
+                    T[s] += u;
+                }
+            }
+            for (int j = jb + 2 + w; j < nt; j += NWK) {
+                const d4 a = *(const d4*)(sx + j * 256 + prow * 16 + 4 * q);
+                const d4 b = *(const d4*)(sx + j * 256 + r * 16 + 4 * q);
+                d4 u0 = mfma16(a[0], b[0], zero), u1 = mfma16(a[1], b[1], zero);
+                u0 = mfma16(a[2], b[2], u0);
+                u1 = mfma16(a[3], b[3], u1);
+                d4* tp = (d4*)(sdiag + j * 256 + r * 16 + 4 * q);
+                *tp = *tp - (u0 + u1);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 //  X = R L^{-T} on 16-row tiles (in place), optional var += rowsumsq(X)
 // ------------------------------------------------------------------------------------------------
 struct TrsmNode {
@@ -1276,9 +1428,17 @@ struct LeafSolveProb {
 
 // LLDS = true: Lc staged in LDS, one 8-wave workgroup per CU.  (LLDS = false - Lc read through L1/L2, two 4-wave workgroups
 // per CU - was measured: 300 B/lane of spills and exposed L2 latency in the solve, 15 % slower over the whole pass; not launched.)
+#ifdef MRA_STAMPS
+#define MRA_LSTAMP(slot) do { if (stamps && threadIdx.x == 0) stamps[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MRA_LSTAMP_ARG , unsigned long long* stamps
+#else
+#define MRA_LSTAMP(slot) do { } while (0)
+#define MRA_LSTAMP_ARG
+#endif
 template <int NTMAX, int CT, bool LLDS>
-__global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_update(const LeafSolveProb* __restrict__ probs) {
+__global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_update(const LeafSolveProb* __restrict__ probs MRA_LSTAMP_ARG) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    MRA_LSTAMP(0);
     constexpr int NTHR = LLDS ? 512 : 256;
     constexpr int NWAVE = NTHR / 64;
     constexpr int NST = (CT * 64 + NTHR - 1) / NTHR;            // 32-byte Ut staging pieces per thread
@@ -1333,6 +1493,7 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
         up[g] = pp->Ut + (long)(on[g] ? e >> 2 : 0) * ldx + ((e & 3) << 2);
     }
     __syncthreads();
+    MRA_LSTAMP(1);
     for (int rg = 0; rg < nrt; rg += NWAVE) {
         const int t = rg + wave;
         const bool valid = t < nrt;
@@ -1374,6 +1535,7 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
         if (valid && q == 0) { double* vp = pp->var + row; gst(vp, gld(vp) - ssq); }
+        if (rg == 0) MRA_LSTAMP(2);
         // ---- update accumulators start from -W (the epilogue writes -acc = W - Tt Ut^T)
         d4 acc[CT];
         double* wp = pp->Wr + row * ldw + 4 * q;
@@ -1383,6 +1545,7 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
 #pragma unroll
         for (int g = 0; g < NST; ++g) if (on[g]) *(d4*)(sU0 + so[g]) = sg[g];
         __syncthreads();
+        if (rg == 0) MRA_LSTAMP(3);
 #pragma unroll
         for (int kb = 0; kb < NTMAX; ++kb) {
             if (kb < nt) {
@@ -1406,10 +1569,12 @@ __global__ __launch_bounds__(LLDS ? 512 : 256, LLDS ? 1 : 2) void k_leaf_solve_u
                 }
             }
         }
+        if (rg == 0) MRA_LSTAMP(4);
         if (valid) {
 #pragma unroll
             for (int j = 0; j < CT; ++j) if (j < nat) gst4(wp + j * 16, -acc[j]);
         }
+        if (rg == 0) MRA_LSTAMP(5);
     }
 }
 
@@ -1507,27 +1672,45 @@ __device__ __forceinline__ void cascade_stage_level(const CascadeArgs& ar, int m
     });
 }
 
-template <int CWT, int NLMAX, int DIM, int MODE>
+template <int CWT, int NLMAX, int DIM, int MODE, bool LAT = false>
 __device__ __forceinline__ void cascade_compute_level_kx(const double* __restrict__ kx, const KernelParams& kp, int m,
                                                          const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
-                                                         const double* xr, int prow, int q, int dbg);
+                                                         const double* xr, int prow, int q, int dbg, const d4* cvp = nullptr);
 template <int CWT, int NLMAX, int DIM, int MODE>
 __device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, const KernelParams& kp, int m, int slot,
                                                       const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
                                                       const double* xr, int prow, int q) {
     cascade_compute_level_kx<CWT, NLMAX, DIM, MODE>(ar.lev[m].kx + (long)slot * (CWT * 16) * DIM, kp, m, ldsb, w, xr, prow, q, ar.dbg);
 }
-template <int CWT, int NLMAX, int DIM, int MODE>
+// LAT: the caller is a latency chain (k_knot_chain: one or two waves per workgroup walk a few rows down while everybody else
+// waits) - four accumulator chains instead of one (a dependent f64 MFMA issues every ~73 ns, an independent one every ~29 ns)
+// and no scheduling fences; the row cascade (many waves per SIMD, register-bound) keeps the single chain.
+// cvp (LAT only): the covariances of the 16 rows with this level's knots, evaluated beforehand (cascade_cov_tiles)
+template <int CWT, int NLMAX, int DIM, int MODE, bool LAT>
 __device__ __forceinline__ void cascade_compute_level_kx(const double* __restrict__ kx, const KernelParams& kp, int m,
                                                          const double* __restrict__ ldsb, d4 (&w)[NLMAX][CWT],
-                                                         const double* xr, int prow, int q, int dbg) {
+                                                         const double* xr, int prow, int q, int dbg, const d4* cvp) {
     constexpr int NTRI = CWT * (CWT - 1) / 2;
     const d4 zero = {0, 0, 0, 0};
     const int nwk = CWT * m * CWT;
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
         d4 acc = zero;
-        if (m > 0) {
+        if (LAT && m > 0) {
+            d4 a0 = zero, a1 = zero, a2 = zero, a3 = zero;
+            const double* ab = ldsb + (jb * (m * CWT)) * 256 + prow * 16 + 4 * q;
+#pragma unroll
+            for (int i = 0; i < NLMAX * CWT; ++i) {
+                if (i < m * CWT) {
+                    const d4 a = *(const d4*)(ab + i * 256);
+                    a0 = mfma16(a[0], w[i / CWT][i % CWT][0], a0);
+                    a1 = mfma16(a[1], w[i / CWT][i % CWT][1], a1);
+                    a2 = mfma16(a[2], w[i / CWT][i % CWT][2], a2);
+                    a3 = mfma16(a[3], w[i / CWT][i % CWT][3], a3);
+                }
+            }
+            acc = (a0 + a1) + (a2 + a3);
+        } else if (m > 0) {
             // the Wk fragment of product i+1 is read while product i issues, and no further ahead (left alone the scheduler
             // hoists every LDS read of the level to the top: up to 56 registers)
             const double* ab = ldsb + (jb * (m * CWT)) * 256 + prow * 16 + 4 * q;
@@ -1544,7 +1727,8 @@ __device__ __forceinline__ void cascade_compute_level_kx(const double* __restric
             }
         }
         d4 res;
-        {
+        if (LAT && cvp) res = cvp[jb] - acc;
+        else {
             double kc[4 * DIM];                     // coordinates of this lane's 4 knots (phantoms: far away)
             const double* kp4 = kx + (long)(jb * 16 + 4 * q) * DIM;
 #pragma unroll
@@ -1552,21 +1736,48 @@ __device__ __forceinline__ void cascade_compute_level_kx(const double* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) res[j] = (MRA_WHATIF_BIT(dbg, 4) ? kc[j * DIM] * 1e-3 : cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular))) - acc[j];
         }
-        d4 upd = zero;
+        d4 upd = zero, upd1 = zero;
 #pragma unroll
         for (int kb = 0; kb < CWT; ++kb) {
             if (kb < jb) {
                 const d4 a = *(const d4*)(ldsb + (nwk + jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
+                if (LAT) {
+                    upd = mfma16(a[0], w[m][kb][0], upd); upd1 = mfma16(a[1], w[m][kb][1], upd1);
+                    upd = mfma16(a[2], w[m][kb][2], upd); upd1 = mfma16(a[3], w[m][kb][3], upd1);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) upd = mfma16(a[j], w[m][kb][j], upd);
+                    for (int j = 0; j < 4; ++j) upd = mfma16(a[j], w[m][kb][j], upd);
+                }
             }
         }
-        res -= upd;
+        res -= LAT ? upd + upd1 : upd;
         const d4 ia = *(const d4*)(ldsb + (nwk + NTRI + jb) * 256 + prow * 16 + 4 * q);
         d4 xx = zero;
+        if (LAT) {
+            d4 x1 = mfma16(ia[1], res[1], zero);
+            xx = mfma16(ia[0], res[0], zero);
+            x1 = mfma16(ia[3], res[3], x1);
+            xx = mfma16(ia[2], res[2], xx);
+            xx += x1;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], res[j], xx);
+            for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], res[j], xx);
+        }
         w[m][jb] = xx;
+    }
+}
+
+// kernel(rows, knots of one level) for the 16 rows of a wave: CWT tiles in the layout cascade_compute_level_kx consumes
+template <int CWT, int DIM, int MODE>
+__device__ __forceinline__ void cascade_cov_tiles(const double* __restrict__ kx, const KernelParams& kp, const double* xr, int q, d4* cv) {
+#pragma unroll
+    for (int jb = 0; jb < CWT; ++jb) {
+        double kc[4 * DIM];
+        const double* kp4 = kx + (long)(jb * 16 + 4 * q) * DIM;
+#pragma unroll
+        for (int e = 0; e < 4 * DIM; e += 4) *(d4*)(kc + e) = *(const d4*)(kp4 + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[jb][j] = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xr, kc + j * DIM, kp.circular));
     }
 }
 
@@ -1796,15 +2007,21 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
 //  factorisation scratch.
 // ------------------------------------------------------------------------------------------------
 struct KnotChainArgs {
-    CascadeLevel lev[8];          // level arrays: kx (in), Wk / L / invd (out)
-    const int* kt_rows[8];        // [node slot][CWT][16] knot rows, -1 = phantom
-    const int* owner[8];          // [node slot] -> workgroup (slot on the last non-leaf level) that writes the node's results
+    CascadeLevel lev[8];          // level arrays: Wk / L / invd (out)
     const int* chain;             // [workgroup][8] node slot per level
-    const double* X;
+    const int* ownmask;           // [workgroup] bit m: this workgroup writes the results of its level-m ancestor (the first workgroup below it)
+    const double* knots;          // [workgroup][level][CW * (DIM + 1)]: the knots' coordinates, then 1.0 (real knot) / 0.0 (phantom) per knot -
+                                  // everything the chain needs from outside, packed per workgroup by the host (mra_plan_set_locs)
     int nl;
     int node_base[8];             // node number of slot 0 per level (error reports)
     int* err;
+    unsigned long long* stamps;   // diagnostic build (-DMRA_STAMPS) only: 64 wall-clock stamps (10 ns) per workgroup
 };
+#ifdef MRA_STAMPS
+#define MRA_KSTAMP() do { if (ka.stamps && threadIdx.x == 0) ka.stamps[(long)blockIdx.x * 64 + kst] = __builtin_amdgcn_s_memrealtime(); ++kst; } while (0)
+#else
+#define MRA_KSTAMP() do { } while (0)
+#endif
 
 template <int CWT, int NLMAX, int DIM, int MODE>
 __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelParams kp) {
@@ -1820,59 +2037,95 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
     const int nl = ka.nl;
     double* const fs = lds + (long)cascade_level_off<CWT>(nl - 1) * 256;     // NT2 lower tiles (FT_SZ each), then CWT inverse tiles
     double* const finv = fs + NT2 * FT_SZ;
+    double* const kxs = finv + CWT * FT_SZ;                                  // [level][CW][DIM] knot coordinates of this chain
+#ifdef MRA_STAMPS
+    int kst = 0;
+#endif
+    MRA_KSTAMP();
+    // ---- everything the chain needs from outside in ONE round trip (addresses depend on the workgroup number only): node slots, owner
+    // bits and the packed knots of every level, into LDS.  (Fetched where they were used - slot -> knot rows -> coordinates, and the
+    // coarser levels' knots in front of every kernel evaluation - these were 2-3 dependent global round trips per level.)
+    constexpr int KREC = CW * (DIM + 1);
+    int slots[NLMAX];
+#pragma unroll
+    for (int k = 0; k < NLMAX; ++k) slots[k] = k < nl ? chain[k] : 0;
+    const int ownbits = ka.ownmask[blockIdx.x];
+    {
+        const double* src = ka.knots + (long)blockIdx.x * nl * KREC;
+        for (int e = threadIdx.x; e < nl * KREC; e += blockDim.x) kxs[e] = src[e];
+    }
+    __syncthreads();
+    MRA_KSTAMP();
+    // CWT == 2: the kernel evaluations of the NEXT level's knot rows against the knots of all coarser levels (software exp and sqrt,
+    // 1 us per coarser level on the one wave that owns the rows - 40 % of the row walk) depend on nothing computed here: the walker
+    // waves do them while the last wave factorises the current level
+    d4 cv[NLMAX][CWT];
+    const int fwave = CWT == 2 ? nwave - 1 : 0;
 #pragma unroll 1
     for (int m = 0; m < nl; ++m) {
-        const int slot = chain[m];
-        const bool own = ka.owner[m][slot] == (int)blockIdx.x;
+        int slot = 0;
+#pragma unroll
+        for (int k = 0; k < NLMAX; ++k) if (k == m) slot = slots[k];
+        const bool own = (ownbits >> m) & 1;
         const bool last = m == nl - 1;
         double* const img = lds + (long)cascade_level_off<CWT>(m) * 256;      // image of level m (unused for the last level)
         const int Kw = m * CW;
         double* const Wk_g = const_cast<double*>(ka.lev[m].Wk) + (long)slot * CW * Kw;
-        const double* kxn = ka.lev[m].kx + (long)slot * CW * DIM;
-        // ---- 1. knot rows down the levels < m: Wk tiles
-        if (wave < CWT && m > 0) {
-            const int rr = ka.kt_rows[m][((long)slot * CWT + wave) * 16 + r];
-            const bool phantom_row = rr < 0;
-            const long myrow = phantom_row ? 0 : rr;
-            double xr[DIM];
+        const double* kxn = kxs + m * KREC;
+        // ---- 1. knot rows down the levels < m: Wk tiles.  The last level has no image of its own (LDS is full), but once its rows
+        //         are through, the images of the first levels are dead: its Wk tiles go there (when they fit) and step 2 reads them
+        //         from LDS instead of making the round trip through global memory (8.7 -> 3 us)
+        const bool walker = wave < CWT && m > 0;
+        const bool wk_lds = !last || CWT * m * CWT <= cascade_level_off<CWT>(m);
+        double* const wimg = last ? lds : img;
+        d4 w[NLMAX][CWT];
+        bool phantom_row = true;
+        if (walker) {
+            double xr[DIM];                                   // this lane's knot row = knot wave * 16 + r of the level's node
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) xr[c] = ka.X[myrow * DIM + c];
-            d4 w[NLMAX][CWT];
+            for (int c = 0; c < DIM; ++c) xr[c] = kxn[(wave * 16 + r) * DIM + c];
+            phantom_row = kxn[CW * DIM + wave * 16 + r] == 0.0;
 #pragma unroll
             for (int k = 0; k < NLMAX; ++k)
-                if (k < m) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE>(ka.lev[k].kx + (long)chain[k] * CW * DIM, kp, k,
-                                                                              lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0);
+                if (k < m) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE, true>(kxs + k * KREC, kp, k,
+                                                                              lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0,
+                                                                              CWT == 2 ? cv[k] : nullptr);
+        }
+        if (last) __syncthreads();                              // every walker is done with the images
+        if (walker) {
 #pragma unroll
             for (int k = 0; k < NLMAX; ++k) {
                 if (k < m) {
 #pragma unroll
                     for (int kt = 0; kt < CWT; ++kt) {
                         const d4 v = phantom_row ? zero : w[k][kt];
-                        if (!last) *(d4*)(img + (long)(wave * (m * CWT) + k * CWT + kt) * 256 + r * 16 + 4 * q) = v;
+                        if (wk_lds) *(d4*)(wimg + (long)(wave * (m * CWT) + k * CWT + kt) * 256 + r * 16 + 4 * q) = v;
                         if (own || last) *(d4*)(Wk_g + (long)(wave * 16 + r) * Kw + (k * CWT + kt) * 16 + 4 * q) = v;
                     }
                 }
             }
         }
         __syncthreads();
+        MRA_KSTAMP();
         // ---- 2. kInv = kernel(knots, knots) - Wk Wk^T, lower tiles into the factorisation scratch
         for (int idx = wave; idx < NT2; idx += nwave) {
             int ib = 0;
             while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
             const int jb = idx - ib * (ib + 1) / 2;
-            d4 acc = zero;
+            d4 acc = zero, acc1 = zero;                      // two chains: a dependent f64 MFMA issues every ~73 ns, an independent one every ~29 ns
             for (int kk = 0; kk < m * CWT; ++kk) {
                 d4 a, b;
-                if (!last) {
-                    a = *(const d4*)(img + (long)(jb * (m * CWT) + kk) * 256 + prow * 16 + 4 * q);
-                    b = *(const d4*)(img + (long)(ib * (m * CWT) + kk) * 256 + r * 16 + 4 * q);
+                if (wk_lds) {
+                    a = *(const d4*)(wimg + (long)(jb * (m * CWT) + kk) * 256 + prow * 16 + 4 * q);
+                    b = *(const d4*)(wimg + (long)(ib * (m * CWT) + kk) * 256 + r * 16 + 4 * q);
                 } else {
                     a = *(const d4*)(Wk_g + (long)(jb * 16 + prow) * Kw + kk * 16 + 4 * q);
                     b = *(const d4*)(Wk_g + (long)(ib * 16 + r) * Kw + kk * 16 + 4 * q);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = mfma16(a[j], b[j], acc);
+                acc = mfma16(a[0], b[0], acc); acc1 = mfma16(a[1], b[1], acc1);
+                acc = mfma16(a[2], b[2], acc); acc1 = mfma16(a[3], b[3], acc1);
             }
+            acc += acc1;
             double xi[DIM];
 #pragma unroll
             for (int c = 0; c < DIM; ++c) xi[c] = kxn[(long)(ib * 16 + r) * DIM + c];
@@ -1883,7 +2136,56 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
             *(d4*)(fs + (long)idx * FT_SZ + r * FT_LD + 4 * q) = res;
         }
         __syncthreads();
+        MRA_KSTAMP();
         // ---- 3. Cholesky of the CW x CW block in LDS (left-looking over column tiles, diagonal blocks on wave 0)
+        if (CWT == 2) {
+            // two column tiles: the whole chain (factor, one row solve, one update, factor) on one wave without workgroup barriers
+            if (wave < CWT && m + 1 < nl) {
+                double xn[DIM];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) xn[c] = kxs[(m + 1) * KREC + (wave * 16 + r) * DIM + c];
+#pragma unroll
+                for (int k = 0; k < NLMAX; ++k)
+                    if (k <= m) cascade_cov_tiles<CWT, DIM, MODE>(kxs + k * KREC, kp, xn, q, cv[k]);
+            }
+            if (wave == fwave) {
+                bool bad = false;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    double a[16], mi[16];
+                    double* dt = fs + (long)(jb * (jb + 1) / 2 + jb) * FT_SZ;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
+                    chol16_inv(a, mi, r, bad, nullptr);
+                    if (lane < 16) {
+#pragma unroll
+                        for (int k = 0; k < 16; k += 2) {
+                            *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
+                            *(d2*)(finv + jb * FT_SZ + lane * FT_LD + k) = d2{mi[k], mi[k + 1]};
+                        }
+                    }
+                    if (jb == 0) {
+                        lds_wave_sync();
+                        const d4 ia = *(const d4*)(finv + prow * FT_LD + 4 * q);
+                        d4* tp = (d4*)(fs + (long)1 * FT_SZ + r * FT_LD + 4 * q);
+                        const d4 b = *tp;
+                        d4 x0 = mfma16(ia[0], b[0], zero), x1 = mfma16(ia[1], b[1], zero);
+                        x0 = mfma16(ia[2], b[2], x0); x1 = mfma16(ia[3], b[3], x1);
+                        *tp = x0 + x1;
+                        lds_wave_sync();
+                        const d4 xa = *(const d4*)(fs + (long)1 * FT_SZ + prow * FT_LD + 4 * q);
+                        const d4 xb = x0 + x1;
+                        d4 u0 = mfma16(xa[0], xb[0], zero), u1 = mfma16(xa[1], xb[1], zero);
+                        u0 = mfma16(xa[2], xb[2], u0); u1 = mfma16(xa[3], xb[3], u1);
+                        d4* dp = (d4*)(fs + (long)2 * FT_SZ + r * FT_LD + 4 * q);
+                        *dp = *dp - (u0 + u1);
+                        lds_wave_sync();
+                    }
+                }
+                if (bad && lane == 0) atomicMax(ka.err, ka.node_base[m] + slot + 1);
+            }
+            __syncthreads();
+        } else
         for (int jb = 0; jb < CWT; ++jb) {
             if (jb > 0) {
                 for (int ib = jb + wave; ib < CWT; ib += nwave) {
@@ -1929,6 +2231,7 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
             }
             __syncthreads();
         }
+        MRA_KSTAMP();
         // ---- 4. factor into the level's image (strictly-lower tiles, inverted diagonal blocks) and, from the owner, into
         //         the level arrays (row-major CW x CW factor with zeros above the diagonal, CWT inverse blocks)
         for (int idx = wave; idx < NT2 + CWT; idx += nwave) {
@@ -1951,6 +2254,7 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
             }
         }
         __syncthreads();
+        MRA_KSTAMP();
     }
 }
 

@@ -452,11 +452,15 @@ static void build_static(mra_plan* pl) {
                 for (int m = 0; m < nlv; ++m) if (own[m][ch[m]] < 0) own[m][ch[m]] = (int)b;
             }
             pl->kc_chain.upload(kch);
-            pl->kc_owner.clear();
-            pl->kc_owner.resize(nlv);
-            for (int m = 0; m < nlv; ++m) pl->kc_owner[m].upload(own[m]);
+            pl->kc_chain_host = kch;
+            std::vector<int> mask(lb.nodes.size(), 0);
+            for (size_t b = 0; b < lb.nodes.size(); ++b)
+                for (int m = 0; m < nlv; ++m) if (own[m][kch[b * 8 + m]] == (int)b) mask[b] |= 1 << m;
+            pl->kc_ownmask.upload(mask);
+            pl->kc_knots.alloc(lb.nodes.size() * (size_t)nlv * cwt * 16 * (pl->d + 1));        // filled by mra_plan_set_locs
             const long off = (long)cwt * cwt * ((nlv - 1) * (nlv - 2) / 2) + (long)(nlv - 1) * (cwt * (cwt - 1) / 2 + cwt);
-            pl->knot_chain_lds = (size_t)off * 2048 + (size_t)(cwt * (cwt + 1) / 2 + cwt) * FT_SZ * sizeof(double);
+            pl->knot_chain_lds = (size_t)off * 2048 + (size_t)(cwt * (cwt + 1) / 2 + cwt) * FT_SZ * sizeof(double)
+                                 + (size_t)nlv * cwt * 16 * (pl->d + 1) * sizeof(double);    // + the chain's knots (coordinates, real/phantom flags)
             pl->knot_chain_ok = pl->knot_chain_lds <= 160 * 1024;
         }
         std::vector<long> r0s, fwg0, lwg0;
@@ -734,6 +738,15 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->gLeafResidLik.upload(grl);
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
     pl->gLeafCholFull.upload(pf); pl->gLeafCholLik.upload(pk); pl->gLeafCholC.upload(pc);
+    {
+        // the same problems with the matrices of at most 8 tiles first (k_chol_tiles<8> at three workgroups per CU, then the few larger ones)
+        std::vector<PanelProb> ps;
+        for (int pass = 0; pass < 2; ++pass)
+            for (const PanelProb& p : pc) if ((p.ne <= 8) == (pass == 0)) ps.push_back(p);
+        pl->n_chol_small = 0;
+        for (const PanelProb& p : pc) if (p.ne <= 8) ++pl->n_chol_small;
+        pl->gLeafCholSorted.upload(ps);
+    }
     for (int v = 0; v < 2; ++v) { pl->gBigPanel[v].clear(); pl->gBigTrail[v].clear(); pl->bigM[v].clear(); pl->bigN[v].clear(); }
     if (pl->leaf_max_nop / 16 > 12) {
         const int NBT = 4;                                        // column tiles per step
@@ -940,11 +953,16 @@ static void run_prior_fused(mra_plan* pl) {
         KnotChainArgs ka{};
         for (int m = 0; m < n_chain; ++m) {
             ka.lev[m] = base.lev[m];
-            ka.kt_rows[m] = pl->fl[m].kt_rows.p;
-            ka.owner[m] = pl->kc_owner[m].p;
             ka.node_base[m] = (int)pl->level_ptr[m];
         }
-        ka.chain = pl->kc_chain.p; ka.X = pl->X.p; ka.nl = n_chain; ka.err = pl->errflag.p;
+        ka.chain = pl->kc_chain.p; ka.ownmask = pl->kc_ownmask.p; ka.knots = pl->kc_knots.p; ka.nl = n_chain; ka.err = pl->errflag.p;
+#ifdef MRA_STAMPS
+        {
+            const size_t need = pl->lev[n_chain - 1].nodes.size() * 64;
+            if (pl->kstamps.n < need) { pl->kstamps.alloc(need); HIP_TRY(mraMemset(pl->kstamps.p, 0, need * sizeof(double))); HIP_TRY(hipDeviceSynchronize()); }
+            ka.stamps = (unsigned long long*)pl->kstamps.p;
+        }
+#endif
         launch_knot_chain(pl, ka);
     }
     for (int m = n_chain; m < pl->NL; ++m) {
@@ -1380,6 +1398,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
             const int ntl = pl->leaf_max_nop / 16;
             if (ntl <= 12) {
+                if (ntl <= 10 && (pl->use_chol_lds == 2 || (pl->use_chol_lds == 1 && nl <= (size_t)(2 * pl->n_cu)))) {
+                    // one workgroup per matrix, tiles in registers, next diagonal block factorised beside the trailing update
+                    const size_t ns = pl->n_chol_small;
+                    if (ns == nl || nl > (size_t)(2 * pl->n_cu)) {
+                        if (ns) hipLaunchKernelGGL((k_chol_tiles<8, 4>), dim3((unsigned)ns), dim3(256), 0, pl->stream, pl->gLeafCholSorted.p, pl->dnode.p, pl->errflag.p);
+                        if (nl > ns) hipLaunchKernelGGL((k_chol_tiles<10, 4>), dim3((unsigned)(nl - ns)), dim3(256), 0, pl->stream, pl->gLeafCholSorted.p + ns, pl->dnode.p, pl->errflag.p);
+                    }
+                    else hipLaunchKernelGGL((k_chol_tiles<10, 4>), dim3((unsigned)nl), dim3(256), 0, pl->stream, pl->gLeafCholSorted.p, pl->dnode.p, pl->errflag.p);
+                } else
                 hipLaunchKernelGGL((k_chol_wave<12>), dim3((unsigned)((nl + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeafCholC.p, (int)nl, pl->dnode.p, pl->errflag.p);
                 const int mt = pred ? pl->leaf_max_tiles_full : pl->leaf_max_tiles_lik;
                 if (fused) {
@@ -1463,10 +1490,18 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 ensure_big_lds(pl, {(const void*)k_leaf_solve_update<8, 13, true>});
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
                 const size_t ns = pl->n_trsm_small;
+#ifdef MRA_STAMPS
+                if (pl->kstamps2.n < pl->n_leaf_solve_half * 8) { pl->kstamps2.alloc(pl->n_leaf_solve_half * 8); HIP_TRY(mraMemset(pl->kstamps2.p, 0, pl->kstamps2.n * sizeof(double))); HIP_TRY(hipDeviceSynchronize()); }
+#define MRA_LSTAMP_VAL , (unsigned long long*)pl->kstamps2.p
+#define MRA_LSTAMP_NUL , (unsigned long long*)nullptr
+#else
+#define MRA_LSTAMP_VAL
+#define MRA_LSTAMP_NUL
+#endif
                 if (pl->leaf_solve_split == 2 && pl->n_leaf_solve_half)
-                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)pl->n_leaf_solve_half), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolveHalf.p);
+                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)pl->n_leaf_solve_half), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolveHalf.p MRA_LSTAMP_VAL);
                 else
-                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p);
+                    hipLaunchKernelGGL((k_leaf_solve_update<8, 13, true>), dim3((unsigned)ns), dim3(512), pl->leaf_solve_lds, pl->stream, pl->gLeafSolve.p MRA_LSTAMP_NUL);
                 if (nl > ns) launch_gemm<EPI_SUB>(pl, pl->gLeafUpdatePlain.p + ns, nl - ns, pl->leaf_max_rows, pl->leaf_max_na);
             } else {
                 KTimer kt(pl, KF_LEAF_UPDATE, pl->fl_leaf_update);
@@ -1618,6 +1653,7 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
         HIP_TRY(mraMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
         if (pl->regular) {
             const int cw = pl->cw[0];
+            std::vector<std::vector<double>> kxh(pl->kc_levels);
             for (int m = 0; m < pl->NL; ++m) {
                 const LevelData& lv = pl->lev[m];
                 std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d);
@@ -1631,6 +1667,23 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
                             kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
                 }
                 HIP_TRY(mraMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
+                if (m < pl->kc_levels) kxh[m].swap(kx);
+            }
+            // k_knot_chain: every workgroup's knots of all its levels in one record (coordinates, then 1.0 / 0.0 = real / phantom)
+            if (pl->kc_levels >= 2 && pl->kc_knots.n) {
+                const int nlv = pl->kc_levels, d = pl->d;
+                const size_t rec = (size_t)cw * (d + 1), nb = pl->lev[nlv - 1].nodes.size();
+                std::vector<double> pk(nb * nlv * rec);
+                for (size_t b = 0; b < nb; ++b)
+                    for (int m = 0; m < nlv; ++m) {
+                        const int sl = pl->kc_chain_host[b * 8 + m];
+                        const int i = pl->lev[m].nodes[sl];
+                        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+                        double* o = pk.data() + (b * nlv + m) * rec;
+                        std::memcpy(o, kxh[m].data() + (size_t)sl * cw * d, (size_t)cw * d * sizeof(double));
+                        for (int c = 0; c < cw; ++c) o[(size_t)cw * d + c] = c < rk ? 1.0 : 0.0;
+                    }
+                HIP_TRY(mraMemcpy(pl->kc_knots.p, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
             }
         }
         pl->have_locs = true;
@@ -1829,6 +1882,8 @@ int mra_get_buffer(mra_plan* pl, int what, double* out, int64_t cap, int64_t* n_
         else if (what == 1) { src = pl->dnode.p; n = (int64_t)pl->dnode.n; }
         else if (what == 2) { src = pl->stamps.p; n = (int64_t)pl->stamps.n; }     // -DMRA_STAMPS builds: raw 64-bit clock stamps
         else if (what == 3) { src = pl->pstamps.p; n = (int64_t)pl->pstamps.n; }
+        else if (what == 5) { src = pl->kstamps.p; n = (int64_t)pl->kstamps.n; }   // same, knot chain
+        else if (what == 6) { src = pl->kstamps2.p; n = (int64_t)pl->kstamps2.n; } // same, fused leaf solve + update
         else if (what == 4) { src = pl->tstamps.p; n = (int64_t)pl->tstamps.n; }   // same, leaf row solves   // same, predictive cascade
         else throw MraError(MRA_ERR_INVALID, "unknown buffer id");
         *n_avail = n;
@@ -1892,6 +1947,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 7) { pl->use_leaf_solve = value != 0; pl->leaf_solve_mode = (int)value; return MRA_OK; }
     if (option == 8) { pl->use_pred_update = value != 0; return MRA_OK; }
     if (option == 10) { pl->leaf_solve_split = value == 2 ? 2 : 1; return MRA_OK; }
+    if (option == 11) { pl->use_chol_lds = (int)value; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
         // wide leaf-residual shape); bits 1, 2, 4 (no Ut scatter / no W stores / constant instead of the kernel) give WRONG results
@@ -1919,6 +1975,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 7: *value = pl->leaf_solve_mode; break;
         case 8: *value = pl->use_pred_update; break;
         case 10: *value = pl->leaf_solve_split; break;
+        case 11: *value = pl->use_chol_lds; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
     }

@@ -194,7 +194,7 @@ struct mra_plan {
     double R = 0.0;
     int reduce_level = -1;
     // device data
-    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps, tstamps;
+    DevVec<double> X, y, W, var, mean, dnode, scal, covsrc, covdiag, stamps, pstamps, tstamps, kstamps, kstamps2;
     double* host_res = nullptr;      // pinned, device-mapped {d, u, below, err} record of the last pass
     double* host_res_dev = nullptr;  // the same memory as the device sees it
     DevVec<int> errflag, knot_idx, row_leaf;
@@ -214,7 +214,7 @@ struct mra_plan {
     DevVec<GemmProb> gLeafResid, gLeafSyrk, gLeafUpdate, gLeafResidLik;
     std::vector<GemmProb> hLeafResid;
     std::vector<int> leaf_nobs_host;
-    DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC;
+    DevVec<PanelProb> gLeafCholFull, gLeafCholLik, gLeafCholC, gLeafCholSorted;
     // leaves with more than 192 observations: right-looking blocked factorisation, 64 columns per step (one panel launch +
     // one trailing-update GEMM per step); [variant 0 full / 1 likelihood-only][step] -> descriptors of all leaves
     std::vector<DevVec<PanelProb>> gBigPanel[2];
@@ -227,6 +227,8 @@ struct mra_plan {
     int leaf_solve_split = 2;             // measured on an eighth of C3: 1.086 -> 1.066 ms
     DevVec<GemmProb> gLeafUpdatePlain;    // the leaf update in that order (for the leaves the fused kernel does not take)
     bool use_leaf_solve = true, leaf_solve_ok = false;
+    int use_chol_lds = 1;                     // leaf Cholesky with one workgroup per matrix (k_chol_tiles): 1 when a CU sees at most two leaves, 2 always, 0 never
+    size_t n_chol_small = 0;
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
     DevVec<long> leaf_row0_dev;
     DevVec<unsigned char> leaf_upd_dev;
@@ -295,7 +297,9 @@ struct mra_plan {
     int kc_levels = 0;                    // levels 0 .. kc_levels-1 go through the chain kernel
     size_t knot_chain_lds = 0;
     DevVec<int> kc_chain;                 // [bottom slot][8]
-    std::vector<DevVec<int>> kc_owner;    // per level [slot] -> owning workgroup
+    std::vector<int> kc_chain_host;
+    DevVec<int> kc_ownmask;               // [bottom slot] bit m: the workgroup writes its level-m ancestor's results
+    DevVec<double> kc_knots;              // [bottom slot][level][cw * (d + 1)] packed knots of the chain (mra_plan_set_locs)
     int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels (4 or 8; 4 measured faster)
     DevVec<long> ft_wg0_leaf;
     DevVec<int> ft_wgn_leaf;
