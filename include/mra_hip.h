@@ -184,6 +184,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
                                       the side stream frees CUs sooner for the front chain; 1: one workgroup per leaf */
 #define MRA_OPT_CHOL_TILES     11  /* leaf Cholesky by one workgroup per matrix with the tiles in registers (k_chol_tiles): 1 (default) when a CU sees
                                       at most two leaves of at most 160 observations (sharded runs), 2 always, 0 never (one wave per matrix, k_chol_wave) */
+#define MRA_OPT_SEG_GEMM_LDS   12  /* 1 (default): the panel columns of the leaves' parents (a segmented product: sum over the children's Ut blocks; deep
+                                      64-wide trees) run on the LDS-tiled GEMM; 0: on the direct-load GEMM */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 /* current value of an option (so that a caller can change one temporarily and put it back) */

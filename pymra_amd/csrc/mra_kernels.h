@@ -418,7 +418,39 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     const double* bp = pb.B + (b_ok ? brow : 0) * pb.ldb + sch;
     const d4 zero = {0, 0, 0, 0};
     d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
-    const int nk = pb.K >> 4;
+    // SET: K may be split into segments (sum over a node's children, GemmSeg; `neg` segments are subtracted): the K loop below then
+    // walks a flat sequence of (segment, 16-column step) pairs, the prefetch running ahead across segment boundaries
+    constexpr bool SEGS = EPI == EPI_SET;
+    const bool segmented = SEGS && pb.nseg > 0;
+    int nk = pb.K >> 4;
+    int it_sg = 0, it_k = 0, it_K = pb.K;
+    bool it_neg = false, it_done = false;
+    auto seg_enter = [&](int s_) -> bool {                  // first segment >= s_ with K > 0
+        for (int sg = s_; sg < pb.nseg; ++sg) {
+            const GemmSeg* g = pb.segs + sg;
+            const int Ks = g->K;
+            if (Ks > 0) {
+                it_sg = sg; it_K = Ks; it_k = 0; it_neg = g->neg != 0;
+                ap = g->A + (a_ok ? arow : 0) * g->lda + sch;
+                bp = g->B + (b_ok ? brow : 0) * g->ldb + sch;
+                return true;
+            }
+        }
+        return false;
+    };
+    if (segmented) {
+        nk = 0;
+        for (int sg = 0; sg < pb.nseg; ++sg) nk += pb.segs[sg].K >> 4;
+        if (!seg_enter(0)) nk = 0;
+    }
+    auto seg_advance = [&]() {                               // one step on; past the end the last step is read again (unconditional loads)
+        if (it_done) return;
+        it_k += 16;
+        if (it_k >= it_K) {
+            const int kl = it_k - 16;
+            if (!seg_enter(it_sg + 1)) { it_done = true; it_k = kl; }
+        }
+    };
     // Global loads run GL_PF K-steps ahead of the MFMAs through GL_PF register sets (statically indexed:
     // the loop is unrolled by GL_PF); the LDS stage is double-buffered.  What-if runs showed this
     // kernel bound by the latency of its operand stream, not by the MFMA pipe (all MFMAs removed:
@@ -427,12 +459,19 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     // LDS; steps past the end re-read the last step): a load inside a branch makes the compiler fall
     // back to s_waitcnt vmcnt(0) in the loop, which waits for the prefetches just issued as well.
     d4 ra[GL_PF], rb[GL_PF];
+    bool rn[GL_PF];
     const int klast = (nk > 0 ? nk - 1 : 0) * 16;
 #pragma unroll
     for (int i = 0; i < GL_PF; ++i) {
-        const int ko = i < nk ? i * 16 : klast;
-        ra[i] = gld4(ap + ko);
-        rb[i] = gld4(bp + ko);
+        if (SEGS && segmented) {
+            ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_neg;
+            seg_advance();
+        } else {
+            const int ko = i < nk ? i * 16 : klast;
+            ra[i] = gld4(ap + ko);
+            rb[i] = gld4(bp + ko);
+            rn[i] = false;
+        }
     }
     // SUB: the C tile this wave is going to update is fetched now, not after the K loop (sixteen
     // dependent 8-byte loads at the tail of every workgroup cost ~0.27 ms of the leaf update)
@@ -452,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
         // tile then costs no registers during the K loop (32 VGPRs = one wave per SIMD of occupancy)
         c00 = -cin[0]; c01 = -cin[1]; c10 = -cin[2]; c11 = -cin[3];
     }
-    *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = a_ok ? ra[0] : zero;
+    *(d4*)(&sA[0][srow * GL_LDS_LD + sch]) = a_ok ? ((SEGS && rn[0]) ? -ra[0] : ra[0]) : zero;
     *(d4*)(&sB[0][srow * GL_LDS_LD + sch]) = b_ok ? rb[0] : zero;
     __syncthreads();
     const int arow0 = (wr0 + r) * GL_LDS_LD + 4 * q, arow1 = arow0 + 16 * GL_LDS_LD;
@@ -499,13 +538,16 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
         for (int i = 0; i < GL_PF; ++i) {
             const int ks = ks0 + i;                        // LDS buffer i & 1 holds step ks (GL_PF is even)
             if (ks < nk) {
-                {                                          // register set i is free again: refill it GL_PF steps ahead
+                if (SEGS && segmented) {                   // register set i is free again: refill it GL_PF steps ahead
+                    ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_neg;
+                    seg_advance();
+                } else {
                     const int ko = (ks + GL_PF < nk) ? (ks + GL_PF) * 16 : klast;
                     ra[i] = gld4(ap + ko);
                     rb[i] = gld4(bp + ko);
                 }
                 compute(i & 1);
-                *(d4*)(&sA[(i + 1) & 1][srow * GL_LDS_LD + sch]) = a_ok ? ra[(i + 1) % GL_PF] : zero;
+                *(d4*)(&sA[(i + 1) & 1][srow * GL_LDS_LD + sch]) = a_ok ? ((SEGS && rn[(i + 1) % GL_PF]) ? -ra[(i + 1) % GL_PF] : ra[(i + 1) % GL_PF]) : zero;
                 *(d4*)(&sB[(i + 1) & 1][srow * GL_LDS_LD + sch]) = b_ok ? rb[(i + 1) % GL_PF] : zero;
                 __syncthreads();
             }
@@ -1683,8 +1725,9 @@ __device__ __forceinline__ void cascade_compute_level(const CascadeArgs& ar, con
     cascade_compute_level_kx<CWT, NLMAX, DIM, MODE>(ar.lev[m].kx + (long)slot * (CWT * 16) * DIM, kp, m, ldsb, w, xr, prow, q, ar.dbg);
 }
 // LAT: the caller is a latency chain (k_knot_chain: one or two waves per workgroup walk a few rows down while everybody else
-// waits) - four accumulator chains instead of one (a dependent f64 MFMA issues every ~73 ns, an independent one every ~29 ns)
-// and no scheduling fences; the row cascade (many waves per SIMD, register-bound) keeps the single chain.
+// waits) - no scheduling fences, the kernel evaluations may come precomputed (cvp); the row cascade (many waves per SIMD,
+// register-bound) keeps the fenced form.  (Four accumulator chains instead of one buy nothing: v_mfma_f64_16x16x4 issues every
+// 64 cycles dependent or not)
 // cvp (LAT only): the covariances of the 16 rows with this level's knots, evaluated beforehand (cascade_cov_tiles)
 template <int CWT, int NLMAX, int DIM, int MODE, bool LAT>
 __device__ __forceinline__ void cascade_compute_level_kx(const double* __restrict__ kx, const KernelParams& kp, int m,
@@ -2112,7 +2155,7 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
             int ib = 0;
             while ((ib + 1) * (ib + 2) / 2 <= idx) ++ib;
             const int jb = idx - ib * (ib + 1) / 2;
-            d4 acc = zero, acc1 = zero;                      // two chains: a dependent f64 MFMA issues every ~73 ns, an independent one every ~29 ns
+            d4 acc = zero, acc1 = zero;
             for (int kk = 0; kk < m * CWT; ++kk) {
                 d4 a, b;
                 if (wk_lds) {

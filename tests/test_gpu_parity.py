@@ -603,6 +603,10 @@ def test_deep_wide_trees_two_kernel_predictive_cascade(hip, n, r, M, oracle):
     m2, v2 = pl.predict()
     assert abs(d + u - lik) <= 1e-13 * abs(lik)
     assert np.max(np.abs(m2 - mean)) < 1e-10 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-10
+    pl.set_option(2, 1); pl.set_option(12, 0)              # the parents' panel product on the direct-load GEMM instead of the LDS-tiled one
+    pl.run(True, False)
+    d, u = pl.likelihood()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
     pl.close()
     if oracle:
         ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
