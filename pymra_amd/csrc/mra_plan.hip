@@ -524,6 +524,7 @@ static void build_static(mra_plan* pl) {
 // leaf descriptors: depend on which rows are observed
 static void build_leaf(mra_plan* pl, const double* y) {
     const size_t nl = pl->leaf_nodes.size();
+    pl->cphantom_valid = false;
     pl->leaf_nop.assign(nl, 0);
     pl->leaf_poff.assign(nl + 1, 0);
     pl->leaf_ioff.assign(nl + 1, 0);
@@ -1283,6 +1284,7 @@ static void finish_run(mra_plan* pl) {
     pl->ran = true;
     pl->split_pending = false;
     pl->pass_open = false;
+    if (errv) pl->cphantom_valid = false;
     if (errv) {
         char b[160];
         snprintf(b, sizeof b, "matrix not positive definite in node %d (Cholesky pivot <= 0 or NaN)", errv - 1);
@@ -1310,6 +1312,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         // the previous pass never reached finish_run (an error was thrown, or a split run was abandoned before
         // mra_run_resume): wait for whatever it left on the two streams, and clear the device error flag that
         // only the last kernel of a pass resets
+        pl->cphantom_valid = false;
         if (pl->side_pending) HIP_TRY(hipStreamWaitEvent(pl->stream, pl->ev_join, 0));
         HIP_TRY(hipStreamSynchronize(pl->stream));
         HIP_TRY(hipStreamSynchronize(pl->stream2));
@@ -1386,7 +1389,13 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                 // nothing to do: the gathered COV product wrote the whole C block including phantom identities
             } else if (pl->leaf_max_nop / 16 <= 12) {
                 // C comes from the COV epilogue, Ut from the gather inside k_trsm_rows2: only the phantom rows remain
-                hipLaunchKernelGGL(k_leaf_cphantom, dim3((unsigned)nl), dim3(256), 0, pl->stream, pl->gLeaf.p, pl->leaf_nobs.p);
+                // ... once: an identity row stays an identity row under the in-place factorisation (L[p][j] = 0, L[p][p] = 1 exactly) and
+                // no epilogue writes there, so later passes find them in place.  (A failed pass - NaN times 0 - a new observation pattern
+                // or a change of options bring the launch back.)
+                if (!pl->cphantom_valid) {
+                    hipLaunchKernelGGL(k_leaf_cphantom, dim3((unsigned)nl), dim3(256), 0, pl->stream, pl->gLeaf.p, pl->leaf_nobs.p);
+                    pl->cphantom_valid = true;
+                }
             } else {
                 const long total = (long)(pl->leaf_max_nop + pl->leaf_max_na) * pl->leaf_max_nop;
                 dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nl);
@@ -1938,6 +1947,7 @@ int mra_get_timers(mra_plan* pl, double* out, int cap) {
 
 int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (!pl) return MRA_ERR_INVALID;
+    pl->cphantom_valid = false;
     if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
     if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }

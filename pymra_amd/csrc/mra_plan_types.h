@@ -229,6 +229,7 @@ struct mra_plan {
     bool use_leaf_solve = true, leaf_solve_ok = false;
     int use_chol_lds = 1;                     // leaf Cholesky with one workgroup per matrix (k_chol_tiles): 1 when a CU sees at most two leaves, 2 always, 0 never
     size_t n_chol_small = 0;
+    bool cphantom_valid = false;              // the phantom observation rows of the leaves' C blocks hold their identity rows
     bool seg_gemm_lds = true;                 // the parents' panel product (segmented: sum over the children's Ut blocks) on the LDS-tiled GEMM (6.3 -> 5.4 ms at config 5)
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
     DevVec<long> leaf_row0_dev;

@@ -469,6 +469,27 @@ def test_not_positive_definite_is_reported(hip):
     assert ei.value.code == -3
 
 
+def test_a_failed_pass_leaves_nothing_behind(hip):
+    """Some buffers are prepared once and trusted afterwards (the identity rows of the leaves' phantom observations survive the
+    in-place Cholesky exactly).  A pass that fails - kernel parameters that make a knot block numerically singular: NaN spreads
+    through the leaves - must not poison the next pass on the same plan."""
+    import pymra_amd.MRATools as mt
+    cs = K.load_case("c2")
+    pl, lik, mean, var = run_hip(hip, cs)
+    s = cs["spec"]
+    pl.set_kernel(mt.KIND_GAUSSIAN, 50.0, 1.0, 1.0)                 # a nearly constant field: numerically singular knot blocks
+    with pytest.raises(hip.MraError) as ei:
+        pl.run(True, True)
+    assert ei.value.code == -3
+    pl.set_kernel(s.kind, s.l, s.sig, s.scale)
+    pl.run(True, True)
+    d, u = pl.likelihood()
+    m2, v2 = pl.predict()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
+    assert np.max(np.abs(m2 - mean)) < 1e-12 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-12
+    pl.close()
+
+
 def test_root_view_attributes(hip):
     import pymra_amd
     import pymra_amd.MRATools as mt
