@@ -2099,11 +2099,35 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
     }
     __syncthreads();
     MRA_KSTAMP();
-    // CWT == 2: the kernel evaluations of the NEXT level's knot rows against the knots of all coarser levels (software exp and sqrt,
-    // 1 us per coarser level on the one wave that owns the rows - 40 % of the row walk) depend on nothing computed here: the walker
-    // waves do them while the last wave factorises the current level
-    d4 cv[NLMAX][CWT];
+    // The knot rows of level m walk down the levels k < m (residual against the coarser bases, whitening by L_k): only the LAST of
+    // these steps needs what the previous iteration has just factorised.  CWT == 2: the walker waves (0, 1) do the steps k < m - 1 of
+    // the NEXT level's rows, and the kernel evaluation of its last step, while the last wave factorises the current level (a
+    // 3.4 us diagonal block, a row solve, an update, another diagonal block: 8.8 us in which they used to wait); after the barrier
+    // they finish with one step.  Other widths (every wave works on the factorisation) walk in one go at the top of the iteration.
+    d4 w[NLMAX][CWT];                                           // the walker's rows: whitened tiles of the levels done so far
+    d4 cvl[CWT];                                                // kernel(rows, knots of the level of the last step)
     const int fwave = CWT == 2 ? nwave - 1 : 0;
+    auto walk_early = [&](int lvl) {                            // rows of level lvl: steps k < lvl - 1, then the kernel tiles of step lvl - 1
+        double xr[DIM];                                         // this lane's knot row = knot wave * 16 + r of the level's node
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) xr[c] = kxs[lvl * KREC + (wave * 16 + r) * DIM + c];
+#pragma unroll
+        for (int k = 0; k < NLMAX; ++k)
+            if (k < lvl - 1) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE, true>(kxs + k * KREC, kp, k,
+                                                                                  lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0, nullptr);
+#pragma unroll
+        for (int k = 0; k < NLMAX; ++k)
+            if (k == lvl - 1) cascade_cov_tiles<CWT, DIM, MODE>(kxs + k * KREC, kp, xr, q, cvl);
+    };
+    auto walk_finish = [&](int lvl) {                           // step lvl - 1 (its level's image is in LDS by now)
+        double xr[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) xr[c] = kxs[lvl * KREC + (wave * 16 + r) * DIM + c];
+#pragma unroll
+        for (int k = 0; k < NLMAX; ++k)
+            if (k == lvl - 1) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE, true>(kxs + k * KREC, kp, k,
+                                                                                   lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0, cvl);
+    };
 #pragma unroll 1
     for (int m = 0; m < nl; ++m) {
         int slot = 0;
@@ -2115,27 +2139,19 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
         const int Kw = m * CW;
         double* const Wk_g = const_cast<double*>(ka.lev[m].Wk) + (long)slot * CW * Kw;
         const double* kxn = kxs + m * KREC;
-        // ---- 1. knot rows down the levels < m: Wk tiles.  The last level has no image of its own (LDS is full), but once its rows
-        //         are through, the images of the first levels are dead: its Wk tiles go there (when they fit) and step 2 reads them
-        //         from LDS instead of making the round trip through global memory (8.7 -> 3 us)
+        // ---- 1. the knot rows' last step, then the Wk tiles out.  The last level has no image of its own (LDS is full), but the images
+        //         of the first levels are dead by then: its Wk tiles go there when they end before the image its walkers still read,
+        //         and step 2 takes them from LDS instead of making the round trip through global memory (8.7 -> 3 us)
         const bool walker = wave < CWT && m > 0;
-        const bool wk_lds = !last || CWT * m * CWT <= cascade_level_off<CWT>(m);
+        const bool wk_lds = !last || (m >= 1 && CWT * m * CWT <= cascade_level_off<CWT>(m - 1));
         double* const wimg = last ? lds : img;
-        d4 w[NLMAX][CWT];
-        bool phantom_row = true;
         if (walker) {
-            double xr[DIM];                                   // this lane's knot row = knot wave * 16 + r of the level's node
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) xr[c] = kxn[(wave * 16 + r) * DIM + c];
-            phantom_row = kxn[CW * DIM + wave * 16 + r] == 0.0;
-#pragma unroll
-            for (int k = 0; k < NLMAX; ++k)
-                if (k < m) cascade_compute_level_kx<CWT, NLMAX, DIM, MODE, true>(kxs + k * KREC, kp, k,
-                                                                              lds + (long)cascade_level_off<CWT>(k) * 256, w, xr, prow, q, 0,
-                                                                              CWT == 2 ? cv[k] : nullptr);
+            if (CWT != 2) walk_early(m);
+            walk_finish(m);
         }
-        if (last) __syncthreads();                              // every walker is done with the images
+        if (last && CWT != 2) __syncthreads();                  // every walker is done with the early images
         if (walker) {
+            const bool phantom_row = kxn[CW * DIM + wave * 16 + r] == 0.0;
 #pragma unroll
             for (int k = 0; k < NLMAX; ++k) {
                 if (k < m) {
@@ -2183,14 +2199,7 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
         // ---- 3. Cholesky of the CW x CW block in LDS (left-looking over column tiles, diagonal blocks on wave 0)
         if (CWT == 2) {
             // two column tiles: the whole chain (factor, one row solve, one update, factor) on one wave without workgroup barriers
-            if (wave < CWT && m + 1 < nl) {
-                double xn[DIM];
-#pragma unroll
-                for (int c = 0; c < DIM; ++c) xn[c] = kxs[(m + 1) * KREC + (wave * 16 + r) * DIM + c];
-#pragma unroll
-                for (int k = 0; k < NLMAX; ++k)
-                    if (k <= m) cascade_cov_tiles<CWT, DIM, MODE>(kxs + k * KREC, kp, xn, q, cv[k]);
-            }
+            if (wave < CWT && m + 1 < nl) walk_early(m + 1);
             if (wave == fwave) {
                 bool bad = false;
 #pragma unroll
