@@ -186,6 +186,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
                                       at most two leaves of at most 160 observations (sharded runs), 2 always, 0 never (one wave per matrix, k_chol_wave) */
 #define MRA_OPT_SEG_GEMM_LDS   12  /* 1 (default): the panel columns of the leaves' parents (a segmented product: sum over the children's Ut blocks; deep
                                       64-wide trees) run on the LDS-tiled GEMM; 0: on the direct-load GEMM */
+#define MRA_OPT_UT_GATHER      13  /* 1 (default): the leaves' Ut = [W_anc[o] | y_o]^T is gathered from W by the row solve (128-byte segments); 0: scattered
+                                      by the prior row cascade in 8-byte pieces (the round-2 path: 0.02 ms slower per C3 pass) */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 /* current value of an option (so that a caller can change one temporarily and put it back) */

@@ -788,6 +788,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         }
     }
     pl->gLeafTrsmFull.upload(tf); pl->gLeafTrsmLik.upload(tk);
+    const std::vector<Trsm2Prob> tfg = tf, tkg = tk;          // with the Ut gather
     for (auto& e : tf) e.gtiles = 0;
     for (auto& e : tk) e.gtiles = 0;
     {
@@ -809,6 +810,13 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->n_trsm_small = 0;
         for (size_t t = 0; t < nl; ++t) if (tf[t].nt <= 8) ++pl->n_trsm_small;
         pl->gLeafTrsmFullPlain.upload(tf2); pl->gLeafTrsmLikPlain.upload(tk2);
+        {
+            std::vector<Trsm2Prob> tf2g, tk2g;                 // same order, Ut gathered from W by the row solve itself
+            for (int pass = 0; pass < 2; ++pass)
+                for (size_t t = 0; t < nl; ++t)
+                    if ((tf[t].nt <= 8) == (pass == 0)) { tf2g.push_back(tfg[t]); tk2g.push_back(tkg[t]); }
+            pl->gLeafTrsmFullPlainG.upload(tf2g); pl->gLeafTrsmLikPlainG.upload(tk2g);
+        }
         {
             // fused row solve + update (k_leaf_solve_update) for the leaves with at most 8 observation tiles, in the same order
             std::vector<LeafSolveProb> sp;
@@ -993,7 +1001,7 @@ static void run_prior_fused(mra_plan* pl) {
 #endif
         ar.var_out = pl->var.p; ar.cov0 = kernel_cov0(pl);
         ar.ycol = pl->Ka; ar.y = pl->y.p;
-        if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0) {
+        if (pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0 && !pl->ut_gather) {
             ar.obs_pos = pl->obs_pos.p; ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p;
             ar.y = pl->y.p;
             // Ut rows follow W's ancestor columns of a last-level leaf: a = column - asuf[NL]
@@ -1425,10 +1433,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                     // cascade at three workgroups per CU)
                     solve_fused = pred && pl->use_leaf_solve && pl->leaf_solve_ok &&
                                   (pl->leaf_solve_mode == 1 || pl->n_trsm_small <= (size_t)(2 * pl->n_cu));
-                    const Trsm2Prob* base = pred ? pl->gLeafTrsmFullPlain.p : pl->gLeafTrsmLikPlain.p;
+                    const Trsm2Prob* likp = pl->ut_gather ? pl->gLeafTrsmLikPlainG.p : pl->gLeafTrsmLikPlain.p;
+                    const Trsm2Prob* base = pred ? (pl->ut_gather ? pl->gLeafTrsmFullPlainG.p : pl->gLeafTrsmFullPlain.p) : likp;
                     const size_t ns = pl->n_trsm_small;
                     const int mts = (pred && !solve_fused) ? pl->trsm_small_tiles_full : pl->trsm_small_tiles_lik;
-                    if (ns) launch_trsm2(pl, solve_fused ? pl->gLeafTrsmLikPlain.p : base, ns, pl->trsm_small_nt, mts, mts);
+                    if (ns) launch_trsm2(pl, solve_fused ? likp : base, ns, pl->trsm_small_nt, mts, mts);
                     // the few leaves with more than 128 observations: several workgroups per leaf when they are few
                     // (one leaf per workgroup would put a single 65 us workgroup on the critical path)
                     if (nl > ns) launch_trsm2(pl, base + ns, nl - ns, ntl, mt, (nl - ns) < 512 ? 4 : mt);
@@ -1959,6 +1968,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 10) { pl->leaf_solve_split = value == 2 ? 2 : 1; return MRA_OK; }
     if (option == 11) { pl->use_chol_lds = (int)value; return MRA_OK; }
     if (option == 12) { pl->seg_gemm_lds = value != 0; return MRA_OK; }
+    if (option == 13) { pl->ut_gather = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
         // wide leaf-residual shape); bits 1, 2, 4 (no Ut scatter / no W stores / constant instead of the kernel) give WRONG results
@@ -1988,6 +1998,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 10: *value = pl->leaf_solve_split; break;
         case 11: *value = pl->use_chol_lds; break;
         case 12: *value = pl->seg_gemm_lds; break;
+        case 13: *value = pl->ut_gather; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));
     }

@@ -220,7 +220,7 @@ struct mra_plan {
     std::vector<DevVec<PanelProb>> gBigPanel[2];
     std::vector<DevVec<GemmProb>> gBigTrail[2];
     std::vector<long> bigM[2], bigN[2];
-    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain;
+    DevVec<Trsm2Prob> gLeafTrsmFull, gLeafTrsmLik, gLeafTrsmFullPlain, gLeafTrsmLikPlain, gLeafTrsmFullPlainG, gLeafTrsmLikPlainG;
     DevVec<LeafSolveProb> gLeafSolve;     // k_leaf_solve_update, same order as the *Plain arrays (leaves with nt <= 8 first)
     DevVec<LeafSolveProb> gLeafSolveHalf; // the small leaves again, two workgroups each (row tiles split in two): shorter workgroups on the
     size_t n_leaf_solve_half = 0;         // side stream free their CUs sooner for the high-priority front chain (MRA_OPT_LEAF_SOLVE_SPLIT)
@@ -229,6 +229,7 @@ struct mra_plan {
     bool use_leaf_solve = true, leaf_solve_ok = false;
     int use_chol_lds = 1;                     // leaf Cholesky with one workgroup per matrix (k_chol_tiles): 1 when a CU sees at most two leaves, 2 always, 0 never
     size_t n_chol_small = 0;
+    bool ut_gather = true;                    // fused path: the leaves' Ut rows gathered from W by the row solve (no scatter in the row cascade: 1.21 -> 1.03 ms there, +0.16 ms in the solve)
     bool cphantom_valid = false;              // the phantom observation rows of the leaves' C blocks hold their identity rows
     bool seg_gemm_lds = true;                 // the parents' panel product (segmented: sum over the children's Ut blocks) on the LDS-tiled GEMM (6.3 -> 5.4 ms at config 5)
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade

@@ -354,9 +354,9 @@ def test_single_launch_chains_equal_per_level_launches(hip, name):
     the launch sequences / kernels they replace."""
     cs = K.load_case(name)
     pl, lik, mean, var = run_hip(hip, cs)
-    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (7, 1, 10, 1), (8, 0), (11, 0), (11, 2), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0, 11, 0)):
+    for opts in ((4, 0), (5, 0), (6, 0), (6, 2), (7, 0), (7, 1), (7, 1, 10, 1), (8, 0), (11, 0), (11, 2), (13, 0), (13, 0, 7, 1), (4, 0, 5, 0, 6, 0, 7, 0, 8, 0, 11, 0)):
         pl.set_option(4, 1); pl.set_option(5, 1); pl.set_option(6, 1); pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(10, 2)
-        pl.set_option(11, 1)
+        pl.set_option(11, 1); pl.set_option(13, 1)
         for o, v in zip(opts[::2], opts[1::2]):
             pl.set_option(o, v)
         pl.run(True, True)
@@ -586,8 +586,8 @@ def test_leaves_without_any_observation(hip):
     pl, lik, mean, var = run_hip(hip, cs)
     assert abs(lik - ref["lik"]) <= 1e-11 * abs(ref["lik"])
     assert np.max(np.abs(mean - ref["mean"])) < 1e-10 and K.rel(np.sqrt(var), ref["sd"]) < 1e-9
-    for opts in ((7, 1), (8, 1, 7, 0), (8, 0, 7, 0), (11, 0), (2, 0)):
-        pl.set_option(2, 1); pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(11, 1)
+    for opts in ((7, 1), (8, 1, 7, 0), (8, 0, 7, 0), (11, 0), (13, 0), (13, 0, 7, 1), (2, 0)):
+        pl.set_option(2, 1); pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(11, 1); pl.set_option(13, 1)
         for o, v in zip(opts[::2], opts[1::2]):
             pl.set_option(o, v)
         pl.run(True, True)
