@@ -1372,6 +1372,11 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
         }
         return pb.invd + (long)(tile - ntri) * 256 + row * 16 + c2;
     });
+    // the gather list of the Ut tiles (the leaf's observed rows) once per workgroup: read per tile from global memory it put a
+    // second round trip in front of every gathered tile's loads
+    int* const sidx = (int*)(lds + (long)(ntri + nt) * 256);
+    if (pb.gtiles > 0 && t_begin < pb.gtiles)
+        for (int e = threadIdx.x; e < nt * 16; e += blockDim.x) sidx[e] = gldi(pb.gidx + e);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int nwave = blockDim.x >> 6;
@@ -1396,7 +1401,7 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
                 if (t < pb.gtiles) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int gi = gldi(pb.gidx + jb * 16 + 4 * q + j);
+                        const int gi = sidx[jb * 16 + 4 * q + j];
                         x[jb][j] = gi < 0 ? 0.0 : gld(pb.gW + (long)gi * pb.gld + t * 16 + r);
                     }
                 } else {

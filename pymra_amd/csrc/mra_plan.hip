@@ -916,7 +916,7 @@ static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int
     if (nt > 12) return false;
     ensure_big_lds(pl, {(const void*)k_trsm_rows2<2>, (const void*)k_trsm_rows2<4>, (const void*)k_trsm_rows2<8>, (const void*)k_trsm_rows2<12>});
     if (pl->prepare_only) return true;
-    const size_t lds = (size_t)(nt * (nt - 1) / 2 + nt) * 2048;
+    const size_t lds = (size_t)(nt * (nt - 1) / 2 + nt) * 2048 + (size_t)nt * 16 * sizeof(int);      // L image + the Ut gather list
     const unsigned gx = (unsigned)((max_tiles + tiles_per_wg - 1) / tiles_per_wg);
     const unsigned tb = 512;
 #ifdef MRA_STAMPS
