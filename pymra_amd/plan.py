@@ -26,6 +26,10 @@ MRA_OPT_KNOT_CHAIN = 5
 MRA_OPT_LEAF_GEMM = 6
 MRA_OPT_LEAF_SOLVE = 7
 MRA_OPT_PRED_UPDATE = 8
+MRA_OPT_LEAF_SOLVE_SPLIT = 10
+MRA_OPT_CHOL_TILES = 11
+MRA_OPT_SEG_GEMM_LDS = 12
+MRA_OPT_UT_GATHER = 13
 MRA_BLOCK_W_ROWS, MRA_BLOCK_LPRIOR, MRA_BLOCK_FRONT, MRA_BLOCK_LEAF = 0, 1, 2, 3
 
 ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4: "MRA_ERR_STATE",

@@ -63,6 +63,17 @@ def test_cov_probe_recognises_device_kernels():
     assert np.allclose(np.asarray(s.evaluate(x, x)), 2.5 * np.asarray(mt.Matern32(x, x, l=0.3, sig=1.5)))
 
 
+def test_option_numbers_agree_with_the_header():
+    """pymra_amd/plan.py repeats the MRA_OPT_* numbers of include/mra_hip.h (ctypes has no header): they must not drift."""
+    import re
+    from pymra_amd import plan as P
+    hdr = open(os.path.join(K.ROOT, "include", "mra_hip.h")).read()
+    defs = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"#define\s+(MRA_OPT_\w+)\s+(\d+)", hdr))
+    assert len(defs) >= 12
+    for name, val in defs.items():
+        assert getattr(P, name) == val, name
+
+
 def test_every_plan_raises_its_own_lds_limits(built_library, tmp_path):
     """The 160 KB dynamic-LDS attribute is per kernel AND per device: it is recorded per plan (a plan lives on one device),
     not behind a process-wide flag - two plans on different device ordinals in one process both take the path.  Host dry
@@ -90,6 +101,13 @@ for dev in (0, 1, 0):
         assert e.code == -1
     pl.set_option(99, 8); assert pl.get_option(99) == 8
     pl.set_option(P.MRA_OPT_FUSED, 0); assert pl.get_option(P.MRA_OPT_FUSED) == 0
+    for opt, val in ((P.MRA_OPT_LEAF_SOLVE_SPLIT, 1), (P.MRA_OPT_CHOL_TILES, 2), (P.MRA_OPT_SEG_GEMM_LDS, 0), (P.MRA_OPT_UT_GATHER, 0)):
+        pl.set_option(opt, val); assert pl.get_option(opt) == val
+    try:
+        pl.set_option(57, 1)
+        raise SystemExit("an unknown option must be refused")
+    except P.MraError as e:
+        assert e.code == -1
     pl.close()
 print("LDS_ATTR_OK", counts)
 assert counts[0] >= 10 and counts[0] == counts[1] == counts[2]
