@@ -67,7 +67,7 @@ enum KFam {
 static const char* kfam_name[3][KF_COUNT] = {
     {"k_gemm_nt_lds<COV> prior residual (unused on the fused path)",
      "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)",
-     "k_prior_cascade row pass (W of all levels, Ut scatter)",
+     "k_prior_cascade row pass (W of all levels)",
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)",
      "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)",

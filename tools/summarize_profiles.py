@@ -4,7 +4,7 @@ import collections, csv, glob, json, os, shutil, sys
 def family(name, grid, maxgrid):
     """rocprof kernel name (+ grid) -> bench.py kernel family name (mra_plan.hip kfam_name[0], the fused path)"""
     if name.startswith("void k_prior_cascade"):
-        return "k_prior_cascade row pass (W of all levels, Ut scatter)" if grid == maxgrid.get("cascade") else KNOT
+        return "k_prior_cascade row pass (W of all levels)" if grid == maxgrid.get("cascade") else KNOT
     if name.startswith("void k_knot_chain"): return KNOT
     if name.startswith("void k_predict_cascade"): return "k_predict_cascade (leaf update + all levels, mean/var)"
     if name.startswith("void k_leaf_gemm<2"): return "k_leaf_gemm<COV> leaf residual V[S,o] and C"
