@@ -187,6 +187,9 @@ def mle_throughput(pl, c, kind, y_obs, l_true=0.1, max_evals=80):
 
 
 def main():
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle: invalid argument otherwise); the
+    # variable is read when the HSA runtime starts, i.e. before the first HIP call of this process - normally the launcher exports it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
