@@ -8,7 +8,8 @@ from pymra_amd.topology import build_topology
 from oracle.mra_levelwise import run_levelwise
 bad = 0
 t0 = time.time()
-for seed in range(100, 160):
+lo, hi = (int(v) for v in os.environ.get("SEEDS", "100:160").split(":"))
+for seed in range(lo, hi):
     rng = np.random.RandomState(seed); np.random.seed(seed)
     d = 1 if seed % 5 == 0 else 2
     if d == 2:
@@ -36,7 +37,13 @@ for seed in range(100, 160):
         print(seed, "oracle:", type(e).__name__, str(e)[:80]); continue
     try:
         pl = P.HipPlan(topo, 0); pl.set_locs(locs); pl.set_obs(y_obs, R); pl.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
-        pl.run(True, True); dd, u = pl.likelihood(); mean, var = pl.predict(); pl.close()
+        pl.run(True, True); dd, u = pl.likelihood(); mean, var = pl.predict()
+        # the same plan again (buffers prepared once must still be right), a likelihood-only pass in between
+        pl.run(True, False); d1, u1 = pl.likelihood()
+        pl.run(True, True); d2, u2 = pl.likelihood(); m2, v2 = pl.predict(); pl.close()
+        again = max(abs(d1 + u1 - dd - u), abs(d2 + u2 - dd - u)) / max(1.0, abs(dd + u)) + float(np.max(np.abs(m2 - mean))) + float(np.max(np.abs(v2 - var)))
+        if again > 1e-11:
+            print(seed, "REPEATED PASSES DIFFER: %.3e" % again); bad += 1
     except Exception as e:
         print(seed, "HIP:", type(e).__name__, str(e)[:100]); bad += 1; continue
     lik = dd + u
