@@ -2926,7 +2926,26 @@ __global__ __launch_bounds__(256) void k_leaf_moments(const LeafProb* __restrict
 struct AsmProb { double* F; int nf; int cw; int child0; int nchild; int add_identity; };
 struct AsmChild { const double* G; long ld; };
 #ifndef MRA_KERNELS_TEMPLATES_ONLY      /* non-template kernel: defined once, in the translation unit of mra_plan.hip */
-__global__ void k_assemble(const AsmProb* __restrict__ probs, const AsmChild* __restrict__ kids, int add_identity) {
+__global__ void k_assemble(const AsmProb* __restrict__ probs, const AsmChild* __restrict__ kids, int add_identity,
+                           const double* __restrict__ sum_in = nullptr, int sum_n = 0, double* __restrict__ sum_out = nullptr) {
+    // sum_in: one more row of workgroups (blockIdx.y == gridDim.y - 1) adds up sum_n log-determinants in order - the reduce level of
+    // a sharded run needs that number beside its assembled fronts, and a launch of its own for it sat on the rank's critical path
+    if (sum_in && blockIdx.y == gridDim.y - 1) {
+        if (blockIdx.x != 0) return;
+        __shared__ double part[256];
+        double s = 0.0;
+        const int chunk = (sum_n + 255) / 256;
+        const int lo = threadIdx.x * chunk, hi = min(sum_n, lo + chunk);
+        for (int i = lo; i < hi; ++i) s += sum_in[i];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 256; ++i) t += part[i];
+            sum_out[0] = t;
+        }
+        return;
+    }
     const AsmProb pb = probs[blockIdx.y];
     const long total = (long)pb.nf * pb.nf;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {

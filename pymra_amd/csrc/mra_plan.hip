@@ -1112,14 +1112,16 @@ static void run_front_level(mra_plan* pl, int m) {
     { KTimer kt(pl, KF_FRONT_SCHUR, lv.fl_schur); launch_gemm<EPI_SUB>(pl, lv.gSchur.p, nn, lv.na, lv.na, false, true); }
 }
 
-static void run_assemble_level(mra_plan* pl, int m, bool with_identity) {
+// sum_in / sum_n / sum_out: also add up that many log-determinants (in order) into *sum_out, in the same launch
+static bool run_assemble_level(mra_plan* pl, int m, bool with_identity, const double* sum_in = nullptr, int sum_n = 0, double* sum_out = nullptr) {
     LevelData& lv = pl->lev[m];
     const size_t nn = lv.nodes.size();
-    if (!nn) return;
+    if (!nn) return false;
     KTimer kt(pl, KF_MISC, 0);
     const long total = (long)lv.nf * lv.nf;
-    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)nn);
-    hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, pl->stream, lv.gAsm.p, pl->asmKids.p, with_identity ? 1 : 0);
+    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 64), (unsigned)(nn + (sum_in ? 1 : 0)));
+    hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, pl->stream, lv.gAsm.p, pl->asmKids.p, with_identity ? 1 : 0, sum_in, sum_n, sum_out);
+    return true;
 }
 
 static void run_add_identity(mra_plan* pl, int m) {
@@ -1135,6 +1137,7 @@ static void finish_run(mra_plan* pl);
 static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
     for (int m = m_from; m >= 0; --m) {
         const bool is_red = (m == pl->reduce_level);
+        bool red_summed = false;             // the reduce level's log-det sum was written by its assembly launch
         bool need_identity = false;          // front sits in global memory without its identity block
         bool assembled = true;
         if (!(resume && m == m_from)) {
@@ -1179,7 +1182,10 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 KTimer kt(pl, KF_FRONT_SCHUR, pl->fl_grand_syrk);
                 launch_gemm<EPI_SET>(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, lg.nf, false, true);      // (LDS-tiled: 24.2 vs 23.7 ms at config 5)
             } else if (is_red) {
-                run_assemble_level(pl, m, false);
+                // (the rank-local log-det sum of everything below rides in the same launch, see the reduce block)
+                LevelData& lvr = pl->lev[m];
+                const int lo_r = (int)pl->level_ptr[m + 1];
+                red_summed = run_assemble_level(pl, m, false, pl->dnode.p + lo_r, pl->n_nodes - lo_r, lvr.F.p + (lvr.F.n - 16));
                 need_identity = true;
             } else {
                 assembled = false;               // the fused front kernel assembles in LDS when the whole front fits
@@ -1189,7 +1195,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 // 16-double tail of the buffer carries the rank-local log-det sum of everything below
                 LevelData& lv = pl->lev[m];
                 const int lo = (int)pl->level_ptr[m + 1];
-                {
+                if (!red_summed) {
                     KTimer kt(pl, KF_MISC, 0);
                     hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p + lo, pl->n_nodes - lo,
                                        lv.F.p + (lv.F.n - 16));
