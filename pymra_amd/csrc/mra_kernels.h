@@ -211,12 +211,17 @@ enum { EPI_SET = 0, EPI_SUB = 1, EPI_COV = 2, EPI_HOSTCOV = 3 };
 //  all tiles of a problem run back to back behind ONE L2 instead of being spread over eight.
 //  Placement is a speed matter only; nothing depends on it for correctness.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool xcd_problem_tile(unsigned G, unsigned nprob, unsigned& prob, unsigned& tile) {
+// Fewer than 8 problems (the top levels of a tree: ONE problem of 4 M rows at level 0 of config 5) would leave XCDs idle - all tiles
+// of a problem behind one L2 means all of them on one XCD: the host then cuts every problem into S = 8, 4 or 2 runs of G consecutive
+// tiles and launches S * nprob virtual problems (virtual problem v = real problem v / S, tiles [(v % S) G, (v % S + 1) G)).
+__device__ __forceinline__ bool xcd_problem_tile(unsigned G, unsigned nprob, unsigned& prob, unsigned& tile, unsigned S = 1) {
     const unsigned lane = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned grp = slot / G;
     tile = slot - grp * G;
     prob = grp * 8u + lane;
-    return prob < nprob;
+    if (prob >= nprob) return false;
+    if (S > 1) { tile += (prob % S) * G; prob /= S; }
+    return true;
 }
 
 // The descriptor is read field by field through a wave-uniform pointer (scalar loads into SGPRs).  A by-value copy
@@ -265,9 +270,9 @@ __device__ __forceinline__ void gemm_nt_emit(const GemmProb* __restrict__ pp, co
 }
 
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
+__global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob, unsigned S = 1) {
     unsigned prob_i, wg_i;
-    if (!xcd_problem_tile(G, nprob, prob_i, wg_i)) return;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i, S)) return;
     const GemmProb* __restrict__ pp = probs + __builtin_amdgcn_readfirstlane(prob_i);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const int pM = pp->M, pN = pp->N;
@@ -390,11 +395,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__
 #define GL_PF 2           /* K-steps the global loads run ahead (register sets); even */
 
 template <int EPI, int DIM, int MODE>
-__global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob) {
+__global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob, unsigned S = 1) {
     __shared__ __attribute__((aligned(16))) double sA[2][64 * GL_LDS_LD];
     __shared__ __attribute__((aligned(16))) double sB[2][64 * GL_LDS_LD];
     unsigned prob_i, wg_i;
-    if (!xcd_problem_tile(G, nprob, prob_i, wg_i)) return;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i, S)) return;
     const GemmProb pb = probs[prob_i];
     const int tn = (pb.N + 63) >> 6, tm = (pb.M + 63) >> 6;
     if ((int)wg_i >= tm * tn) return;

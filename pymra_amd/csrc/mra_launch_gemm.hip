@@ -18,9 +18,16 @@ static void launch_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob, long 
     // 1-D grid, XCD-aware (xcd_problem_tile): gx workgroups per problem, problems rounded up to 8
     const size_t chunk = (size_t)std::max<long>(8, ((0x7fffffffL / (long)gx) / 8) * 8);
     for (size_t off = 0; off < nprob; off += chunk) {
-        const unsigned gy = (unsigned)std::min<size_t>(chunk, nprob - off);
-        dim3 grid(gx * (((gy + 7u) / 8u) * 8u));
-#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp, gx, gy)
+        unsigned gy = (unsigned)std::min<size_t>(chunk, nprob - off);
+        // fewer than 8 problems: every problem cut into S runs of tiles, S * gy virtual problems over the 8 XCD lanes (xcd_problem_tile)
+        unsigned S = 1, gxs = gx;
+        if (gy < 8u && gx >= 8u) {
+            S = gy == 1 ? 8u : (gy == 2 ? 4u : (gy <= 4 ? 2u : 1u));
+            gxs = (gx + S - 1) / S;
+            gy *= S;
+        }
+        dim3 grid(gxs * (((gy + 7u) / 8u) * 8u));
+#define MRA_GEMM_LAUNCH(KERN, D, MD) hipLaunchKernelGGL((KERN<EPI, D, (EPI == EPI_COV ? MD : 0)>), grid, dim3(256), 0, pl->stream, probs + off, pl->kp, gxs, gy, S)
         if (lds) {
             if (pl->d == 1) { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 1, 3); }
             else { if (mode == 0) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 0); else if (mode == 1) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 1); else if (mode == 2) MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 2); else MRA_GEMM_LAUNCH(k_gemm_nt_lds, 2, 3); }
