@@ -70,5 +70,56 @@ int main() {
         }
         hipFree(A); hipFree(B); hipFree(C); hipFree(dp);
     }
+    // ---- the grandparents' signed SYRK of config 5: M = N = 464 (lower), K = 768 as 16 leaf segments of 32 + 4 child segments of 64,
+    //      against the same K in fewer, longer segments: is the segment structure what holds it at 33 TFLOP/s?
+    {
+        const int nprob = 1024, M = 464, Ktot = 768;
+        double* A = dalloc<double>((size_t)nprob * M * Ktot);
+        double* C = dalloc<double>((size_t)nprob * M * M);
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, A, (size_t)nprob * M * Ktot, 5ull);
+        struct Var { const char* name; std::vector<int> ks; };
+        std::vector<Var> vars;
+        { Var v{"20 segments (16 x 32 + 4 x 64)", {}}; for (int i = 0; i < 16; ++i) v.ks.push_back(32); for (int i = 0; i < 4; ++i) v.ks.push_back(64); vars.push_back(v); }
+        { Var v{"5 segments (512 + 4 x 64)", {512, 64, 64, 64, 64}}; vars.push_back(v); }
+        { Var v{"1 segment (768)", {768}}; vars.push_back(v); }
+        { Var v{"48 segments of 16", {}}; for (int i = 0; i < 48; ++i) v.ks.push_back(16); vars.push_back(v); }
+        for (const Var& v : vars) {
+            std::vector<GemmSeg> hs;
+            std::vector<GemmProb> hp(nprob);
+            for (int p = 0; p < nprob; ++p) {
+                double* base = A + (size_t)p * M * Ktot;
+                size_t off = 0;
+                const size_t first = hs.size();
+                for (int k : v.ks) { hs.push_back(GemmSeg{base + off, base + off, k, k, k, 0}); off += (size_t)M * k; }      // each segment its own M x k block
+                GemmProb g{};
+                g.C = C + (size_t)p * M * M; g.ldc = M; g.M = M; g.N = M; g.lower = 1; g.nseg = (int)v.ks.size();
+                g.A = g.B = base; g.K = 0;
+                hp[p] = g;
+                hp[p].segs = (const GemmSeg*)first;                 // index for now, pointer below
+            }
+            GemmSeg* ds = dalloc<GemmSeg>(hs.size());
+            hipMemcpy(ds, hs.data(), hs.size() * sizeof(GemmSeg), hipMemcpyHostToDevice);
+            for (int p = 0; p < nprob; ++p) hp[p].segs = ds + (size_t)hp[p].segs;
+            GemmProb* dp = dalloc<GemmProb>(nprob);
+            hipMemcpy(dp, hp.data(), nprob * sizeof(GemmProb), hipMemcpyHostToDevice);
+            const long tm = (M + 31) / 32;
+            const unsigned gx_dir = (unsigned)((tm * (tm + 1) / 2 + 3) / 4);
+            const unsigned gx_lds = (unsigned)(((M + 63) / 64) * ((M + 63) / 64));
+            for (int which = 0; which < 2; ++which) {
+                float ms = 0;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0);
+                    if (which == 0) hipLaunchKernelGGL((k_gemm_nt<EPI_SET, 2, 0>), dim3(gx_dir * nprob), dim3(256), 0, 0, dp, kp, gx_dir, (unsigned)nprob, 1u);
+                    else hipLaunchKernelGGL((k_gemm_nt_lds<EPI_SET, 2, 0>), dim3(gx_lds * nprob), dim3(256), 0, 0, dp, kp, gx_lds, (unsigned)nprob, 1u);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    hipEventElapsedTime(&ms, e0, e1);
+                }
+                const double fl = (double)M * M * Ktot * nprob;      // lower triangle: half of 2 M N K
+                printf("SYRK 464 lower, K = 768: %-34s %-14s %8.3f ms %7.2f TFLOP/s (triangle count)\n", v.name, which ? "k_gemm_nt_lds" : "k_gemm_nt", ms, fl / ms / 1e9);
+            }
+            hipFree(ds); hipFree(dp);
+        }
+        hipFree(A); hipFree(C);
+    }
     return 0;
 }
