@@ -16,7 +16,7 @@ python3 bench.py --config c5 --likelihood-only --steps 5 --warmup 2 --no-cpu-bas
 python3 tools/shard_timing.py 1 2 4 8 > "$P/${TAG}_shard_emulation_2_4_8.txt" 2>&1
 python3 tools/e2e_breakdown.py > "$P/${TAG}_e2e_breakdown.txt" 2>&1
 bash tools/trace_kernels.sh 1gpu -- python3 tools/one_pass.py 1 > "$P/${TAG}_trace_one_pass_1gpu.txt" 2>&1
-NSUM=2 bash tools/trace_kernels.sh 8way -- python3 tools/one_pass.py 8 > "$P/${TAG}_trace_one_pass_8way_shard_rank0.txt" 2>&1
+bash tools/trace_kernels.sh 8way -- python3 tools/one_pass.py 8 > "$P/${TAG}_trace_one_pass_8way_shard_rank0.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${TAG}_c5" -- python3 bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > "$P/c5_kt.log" 2>&1
 cp $(ls -t gpurun_out/prof_${TAG}_c5/*/*_kernel_stats.csv | head -1) "$P/${TAG}_c5_rocprofv3_kernel_stats.csv"
 rm -f "$P"/*.err "$P"/*.log
