@@ -470,9 +470,19 @@ static void build_static(mra_plan* pl) {
             hipDeviceProp_t prop;
             if (!g_dry && hipGetDeviceProperties(&prop, pl->device) == hipSuccess && prop.multiProcessorCount > 0) ndev_cu = prop.multiProcessorCount;
             size_t nparents = 0;
-            for (size_t t = 0; t < pl->leaf_nodes.size(); ++t)
+            long ntiles_all = 0;
+            for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
                 if (t == 0 || pl->parent[pl->leaf_nodes[t]] != pl->parent[pl->leaf_nodes[t - 1]]) ++nparents;
-            pl->cascade_group_siblings = nparents >= (size_t)(2 * ndev_cu);
+                ntiles_all += (pl->row1[pl->leaf_nodes[t]] - pl->row0[pl->leaf_nodes[t]]) / 16;
+            }
+            // one workgroup (8 waves, the whole LDS) per leaf or per family of sibling leaves: rounds of workgroups over the CUs times
+            // [staging the operand image (~5 us, exposed: one workgroup per CU) + rounds of 8 row tiles (~32 us each)].  Measured on
+            // shards of C3: 256 families on 256 CUs = one round of 64 tiles (261 us) against four rounds of 16 (316 us); 128 families
+            // leave half the CUs idle (261 against 158 us).
+            const size_t nl_ = std::max<size_t>(1, pl->leaf_nodes.size()), np_ = std::max<size_t>(1, nparents);
+            const double t_leaf = std::ceil((double)ntiles_all / nl_ / 8.0), t_fam = std::ceil((double)ntiles_all / np_ / 8.0);
+            const double cost_leaf = std::ceil((double)nl_ / ndev_cu) * (5.0 + 32.0 * t_leaf), cost_fam = std::ceil((double)np_ / ndev_cu) * (5.0 + 32.0 * t_fam);
+            pl->cascade_group_siblings = cost_fam < cost_leaf;
         }
         for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
             const int i = pl->leaf_nodes[t];
