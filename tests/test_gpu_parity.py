@@ -490,6 +490,25 @@ def test_a_failed_pass_leaves_nothing_behind(hip):
     pl.close()
 
 
+def test_repeated_passes_are_bit_identical(hip):
+    """Nothing a pass leaves behind may change the next one: twenty passes on one plan (likelihood-only passes mixed in, a detour
+    through other kernel parameters) reproduce the first bit for bit (tools/soak_passes.py does 500 on C3)."""
+    cs = K.load_case("c2")
+    pl, lik, mean, var = run_hip(hip, cs)
+    mean, var = mean.copy(), var.copy()
+    s = cs["spec"]
+    for i in range(20):
+        if i == 7:
+            pl.set_kernel(s.kind, 0.6 * s.l, s.sig, s.scale); pl.run(True, True)
+            pl.set_kernel(s.kind, s.l, s.sig, s.scale)
+        pl.run(True, i % 3 != 0)
+    pl.run(True, True)
+    d, u = pl.likelihood()
+    m2, v2 = pl.predict()
+    assert d + u == lik and np.array_equal(m2, mean) and np.array_equal(v2, var)
+    pl.close()
+
+
 def test_root_view_attributes(hip):
     import pymra_amd
     import pymra_amd.MRATools as mt
