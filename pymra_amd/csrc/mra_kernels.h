@@ -2352,6 +2352,7 @@ struct PredArgs {
     // UPD: the leaf update W[S, anc | y] -= Tt Ut^T is applied to the row tile in registers before the levels are walked
     // (the updated W is never written: 1.7 GB of stores and 1.7 GB of re-reads less at C3)
     const int* tile_leaf;     // [tile] leaf number
+    const int* wg_leaf;       // [workgroup] leaf number of the workgroup's tiles (they share one): known one round trip before tile_leaf[t0]
     double* const* leaf_ut;   // [leaf] solved Ut block (na x nop), followed by the leaf's Tt rows (N_j x nop)
     const int* leaf_nop;      // [leaf]
     const long* leaf_row0;    // [leaf] first padded row
@@ -2437,7 +2438,7 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     MRA_PSTAMP_WALL(13);
     bool pre_issued = false;
     if (UPD) {
-        const int lf = ar.tile_leaf[t0];                    // all tiles of a workgroup belong to one leaf
+        const int lf = ar.wg_leaf[blockIdx.x];              // all tiles of a workgroup belong to one leaf
         const int nc = ar.leaf_upd[lf] ? (ar.leaf_nop[lf] >> 3) : 0;      // chunks of 8 k
         if (nc > 0) {
             const long nop = ar.leaf_nop[lf];

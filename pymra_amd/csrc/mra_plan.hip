@@ -514,11 +514,11 @@ static void build_static(mra_plan* pl) {
             size_t deep = 0;
             for (const auto& l : lane) deep = std::max(deep, l.size());
             std::vector<long> x0(deep * 8, 0);
-            std::vector<int> xn(deep * 8, 0);
+            std::vector<int> xn(deep * 8, 0), xl(deep * 8, 0);
             for (size_t k = 0; k < deep; ++k)
                 for (size_t x = 0; x < 8; ++x)
-                    if (k < lane[x].size()) { x0[k * 8 + x] = fwg0[lane[x][k]]; xn[k * 8 + x] = fwgn[lane[x][k]]; }
-            pl->ft_wg0_x.upload(x0); pl->ft_wgn_x.upload(xn); pl->n_fwg_x = (long)x0.size();
+                    if (k < lane[x].size()) { x0[k * 8 + x] = fwg0[lane[x][k]]; xn[k * 8 + x] = fwgn[lane[x][k]]; xl[k * 8 + x] = tleaf[(size_t)fwg0[lane[x][k]]]; }
+            pl->ft_wg0_x.upload(x0); pl->ft_wgn_x.upload(xn); pl->ft_wgleaf_x.upload(xl); pl->n_fwg_x = (long)x0.size();
         }
         {
             const int cwt = pl->CWT, mmax = pl->NL - 1;
@@ -1078,7 +1078,7 @@ static void run_predict_fused(mra_plan* pl) {
     fl.bytes = 8.0 * pl->P * (pl->ldw + 3);                // W once in, var in/out, mean out (the level operands stay in L2)
     if (pl->pred_update_now) {
         // the leaf update rides in this launch (two Ut chunk stages share the LDS with the level operands)
-        ar.tile_leaf = pl->ft_leaf.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
+        ar.tile_leaf = pl->ft_leaf.p; ar.wg_leaf = pl->ft_wgleaf_x.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
         ar.leaf_upd = pl->leaf_upd_dev.p; ar.na = pl->na[pl->NL];
         lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 128) * sizeof(double));      // two 8-k chunks of Ut
         fl += Work(pl->fl_leaf_update.alg, pl->fl_leaf_update.exec, pl->by_leaf_tt + pl->by_leaf_ut);    // Tt and Ut in, nothing out

@@ -289,7 +289,7 @@ struct mra_plan {
     };
     std::vector<FusedLevel> fl;
     DevVec<long> ft_row0, ft_wg0, ft_wg0_x;
-    DevVec<int> ft_chain, ft_wgn, ft_wgn_x;
+    DevVec<int> ft_chain, ft_wgn, ft_wgn_x, ft_wgleaf_x;
     long n_ftiles = 0, n_fwg = 0, n_fwg_x = 0;
     size_t cascade_lds = 0, cascade_lds_all = 0;
     bool cascade_stage_all = false;   // all levels' operands fit in LDS: one workgroup per leaf, staged once
