@@ -150,6 +150,44 @@ def shard_topology(topo: Topology, n_ranks: int, rank: int) -> Tuple[Topology, i
     return local, s - 1
 
 
+def sharded_minimize(evaluate, x0, rank: int, bcast, transform=None, **options):
+    """Nelder-Mead over one kernel parameter with a SHARDED objective (BASELINE config 5; the reference's pattern is
+    scipy.optimize.minimize(..., method='nelder-mead') around a new MRATree per call, pyMRA/README.md:96-104,
+    pyMRA/tests/test-param-est.py:81-123).
+
+    ``evaluate(kappa)`` is a collective: every rank calls it with the same ``kappa`` (it runs the rank's local plan up to
+    the one front all-reduce and finishes the upper levels redundantly), and every rank gets the same -2 loglik back.
+    Only rank 0 runs the optimiser; before every objective call it broadcasts ``[1, kappa]`` so that all ranks evaluate
+    the same point, and ``[0, kappa_hat]`` when it is done.  ``bcast(buf)`` broadcasts a float64 array of 2 from rank 0
+    in place (torch.distributed.broadcast on a CPU tensor; any other transport will do).
+
+    Returns (kappa_hat, objective at kappa_hat, [(kappa, objective), ...] of this rank's evaluations, scipy result or None)."""
+    tf = transform or (lambda p: float(abs(p)) + 1e-3)
+    calls = []
+    if rank == 0:
+        import scipy.optimize as opt
+
+        def obj(p):
+            kappa = tf(p[0])
+            bcast(np.array([1.0, kappa]))
+            v = float(evaluate(kappa))
+            calls.append((kappa, v))
+            return v
+        opts = {"xatol": 1e-3, "disp": False}
+        opts.update(options)
+        res = opt.minimize(obj, [float(x0)], method="nelder-mead", options=opts)
+        k_hat = tf(res.x[0])
+        bcast(np.array([0.0, k_hat]))
+        return k_hat, float(res.fun), calls, res
+    while True:
+        msg = np.zeros(2)
+        bcast(msg)
+        if msg[0] == 0.0:
+            best = min(calls, key=lambda kv: kv[1])[1] if calls else float("nan")
+            return float(msg[1]), best, calls, None
+        calls.append((float(msg[1]), float(evaluate(float(msg[1])))))
+
+
 def sharded_run(plan, reduce_level: int, allreduce=None, likelihood=True, predict=True):
     """Run a (local) plan with the single front all-reduce.
 
