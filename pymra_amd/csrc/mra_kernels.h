@@ -2368,35 +2368,76 @@ struct PredArgs {
 #define MRA_PSTAMP_WALL(slot) do { } while (0)
 #endif
 
-#define MRA_PRED_STAGE_ISSUE(ms) MRA_PRED_STAGE_ISSUE_L(ms, ar.lev[ms])
-#define MRA_PRED_STAGE_ISSUE_L(ms, lvl) do { \
+// ---- staging of a level's operand tiles in TWO HALVES --------------------------------------------------------------------------
+// The LDS image of level m lists its tiles in the order the products consume them:
+//     slot 0 .. NTRI-1            strictly-lower tiles of Lt            (solve)
+//     slot NTRI .. NTRI+CWT-1     inverted diagonal blocks              (solve)
+//     then CWT tiles [jb] per front row block, ancestors first: k = 0 .. m-1, kt = 0 .. CWT-1  (front row block a = (m-1-k) CWT + kt,
+//     the level updates w[k][kt]), then the y row block (a = m CWT).
+// Half A = the solve tiles + the row blocks of the first kA = m / 2 ancestor levels, half B = the rest.  A thread holds only ONE half
+// in registers at a time (the loads of half B fly while the products of half A issue, those of the next level's half A during the
+// products of half B): 7 staging registers pairs at C3 instead of 13 - holding a whole level cost the predictive cascade 84 B / lane
+// of scratch at three workgroups per CU (0.4 GB of scratch write-back per launch).  Half A sits at the start of the LDS image,
+// half B at a fixed offset (the size of the deepest level's half A), so neither overwrites what the other half's products read.
+// Levels whose whole image fits the registers of one half are staged in one piece (kA = m, half B empty).
+template <int CWT> __device__ __forceinline__ constexpr int pred_tiles_a(int m, int ka) { return CWT * (CWT - 1) / 2 + CWT + ka * CWT * CWT; }
+template <int CWT> __device__ __forceinline__ constexpr int pred_tiles_all(int m) { return CWT * (CWT - 1) / 2 + CWT + (m * CWT + 1) * CWT; }
+template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int pred_half_regs() {
+    int mx = 0;
+    for (int m = 0; m < NLMAX; ++m) {
+        const int ta = pred_tiles_a<CWT>(m, m / 2), tb = pred_tiles_all<CWT>(m) - ta;
+        mx = ta > mx ? ta : mx;
+        mx = tb > mx ? tb : mx;
+    }
+    return (mx * 128 + NTH - 1) / NTH;
+}
+// tiles of level m in half A: the solve tiles + the row blocks of m / 2 ancestor levels, or the whole level (y included, half B
+// empty) when it fits one half's registers
+template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int pred_sa(int m) {
+    return pred_tiles_all<CWT>(m) * 128 <= pred_half_regs<CWT, NLMAX, NTH>() * NTH ? pred_tiles_all<CWT>(m) : pred_tiles_a<CWT>(m, m / 2);
+}
+// issue the loads of LDS slots [S0, S0 + CNT) of level ms (operands of node chain[ms]) into pre[].  A tile is 128 pieces of 16
+// bytes, a wave moves half a tile per step, so WHICH tile a wave moves in step i is wave-uniform (tl = i TPS + wv): the tile
+// decoding runs on the scalar unit, without divergence, and the address is a scalar base plus ONE per-thread offset (row and
+// column of the piece inside its tile: thread constants; times the front's row stride for the tiles that come out of F) - with a
+// per-thread tile index the seven addresses of a range cost fourteen registers and a page of VALU code per range.
+#define MRA_PRED_ISSUE_RANGE(ms, lvl, S0, CNT) do { \
                 const int ms_ = (ms); \
                 const PredLevel ls = (lvl); \
                 const int slot_s = chain[ms_]; \
                 const double* Fs = ls.F + (long)slot_s * ls.stride; \
                 const double* invs = ls.invF + (long)slot_s * CWT * 256; \
-                const int total = (NTRI + CWT + (ms_ * CWT + 1) * CWT) * 128; \
+                const int cnt_ = (CNT), s0_ = (S0); \
+                const unsigned vz = (unsigned)(prow_c * ls.ld + pcol_c) * 8u, vi = (unsigned)(prow_c * 16 + pcol_c) * 8u; \
 _Pragma("unroll") \
-                for (int i = 0; i < PMAX; ++i) { \
-                    if (i * NTH < total) { \
-                        int e = (int)threadIdx.x + i * NTH; \
-                        e = e < total ? e : total - 1; \
-                        const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1; \
-                        const double* src; \
-                        if (tile < NTRI) { \
-                            int jb = 1; \
+                for (int i = 0; i < PH; ++i) { \
+                    if (i * TPS < cnt_) { \
+                        /* straight-line scalar decode (selects, no branches: the loads of a range stay in one block and issue together); \
+                           a wave whose tile lies beyond the range re-reads the last one */ \
+                        const int tl = i * TPS + wv; \
+                        const int tile = s0_ + (tl < cnt_ ? tl : cnt_ - 1); \
+                        const bool is_tri = tile < NTRI, is_inv = !is_tri && tile < NTRI + CWT; \
+                        int jbt = 1; \
 _Pragma("unroll") \
-                            for (int c = 1; c < CWT - 1; ++c) jb += (tile >= c * (c + 1) / 2) ? 1 : 0; \
-                            const int kb = tile - jb * (jb - 1) / 2; \
-                            src = Fs + (long)(jb * 16 + row) * ls.ld + kb * 16 + c2; \
-                        } else if (tile < NTRI + CWT) { \
-                            src = invs + (long)(tile - NTRI) * 256 + row * 16 + c2; \
-                        } else { \
-                            const int zt = tile - NTRI - CWT, a = zt / CWT, jb = zt % CWT; \
-                            src = Fs + (long)(CW + a * 16 + row) * ls.ld + jb * 16 + c2; \
-                        } \
-                        pre[i] = *(const d2*)src; \
+                        for (int c = 1; c < CWT - 1; ++c) jbt += (tile >= c * (c + 1) / 2) ? 1 : 0; \
+                        const int kbt = tile - jbt * (jbt - 1) / 2; \
+                        const int zt = tile >= NTRI + CWT ? tile - NTRI - CWT : 0, g = zt / CWT, jbz = zt % CWT;   /* g: consumption order of the row blocks */ \
+                        const int az = g < ms_ * CWT ? (ms_ - 1 - g / CWT) * CWT + g % CWT : ms_ * CWT; \
+                        const long rowoff = is_tri ? jbt * 16 : CW + az * 16; \
+                        const int coloff = is_tri ? kbt * 16 : jbz * 16; \
+                        const char* sbF = (const char*)(Fs + rowoff * ls.ld + coloff); \
+                        const char* sbI = (const char*)(invs + (long)(is_inv ? tile - NTRI : 0) * 256); \
+                        pre[i] = *(const d2*)((is_inv ? sbI : sbF) + (is_inv ? vi : vz)); \
                     } \
+                } \
+} while (0)
+// write the CNT tiles held in pre[] to LDS, starting at tile offset T0
+#define MRA_PRED_WRITE_RANGE(T0, CNT) do { \
+                const int cnt_ = (CNT); \
+                char* lb = (char*)lds + ((long)(T0) + wv) * 2048 + pidx_c * 16; \
+_Pragma("unroll") \
+                for (int i = 0; i < PH; ++i) { \
+                    if (i * TPS < cnt_ && i * TPS + wv < cnt_) *(d2*)(lb + i * TPS * 2048) = pre[i]; \
                 } \
 } while (0)
 template <int CWT, int NLMAX, int WPW, bool UPD, int MINB>
@@ -2405,11 +2446,15 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     constexpr int CW = CWT * 16;
     constexpr int NTRI = CWT * (CWT - 1) / 2;
     constexpr int NTH = 64 * WPW;
-    // staging registers: the 16-byte chunks of one level's operand tiles this thread moves (level m has
-    // NTRI + CWT + (m CWT + 1) CWT tiles of 128 chunks)
-    constexpr int PMAX = ((NTRI + CWT + ((NLMAX - 1) * CWT + 1) * CWT) * 128 + NTH - 1) / NTH;
-    d2 pre[PMAX];
+    // staging registers: the 16-byte chunks of HALF a level's operand tiles this thread moves (see MRA_PRED_ISSUE_RANGE)
+    constexpr int PH = pred_half_regs<CWT, NLMAX, NTH>();
+    constexpr int TPS = NTH / 128;                            // tiles the workgroup moves per staging step
+    d2 pre[PH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    // staging coordinates: this thread's piece of a tile (pidx_c of 128: row prow_c, first column pcol_c) and, wave-uniform,
+    // which of the TPS tiles of a step its wave works on
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
+    const int pidx_c = (int)threadIdx.x & 127, prow_c = pidx_c >> 3, pcol_c = (pidx_c & 7) << 1;
     const long t0 = ar.wg_tile0[blockIdx.x];
     const int nt_wg = ar.wg_ntiles[blockIdx.x];
     if (nt_wg == 0) return;                                 // padding slot of the XCD-dealt workgroup order
@@ -2437,6 +2482,12 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     MRA_PSTAMP(0);
     MRA_PSTAMP_WALL(13);
     bool pre_issued = false;
+    // tile offset of half B in the LDS image: the size of the deepest level's half A (no shallower level's half A is larger
+    // unless it is staged in one piece, and then nothing of a half B is alive any more)
+    const int offb = pred_sa<CWT, NLMAX, NTH>(ar.nl - 1);
+// half A of the deepest level (a run-time level number: ar.deep = ar.lev[ar.nl - 1], a run-time index into lev[] would put the
+// whole argument block in scratch)
+#define MRA_PRED_ISSUE_DEEP_A() MRA_PRED_ISSUE_RANGE(ar.nl - 1, ar.deep, 0, offb)
     if (UPD) {
         const int lf = ar.wg_leaf[blockIdx.x];              // all tiles of a workgroup belong to one leaf
         const int nc = ar.leaf_upd[lf] ? (ar.leaf_nop[lf] >> 3) : 0;      // chunks of 8 k
@@ -2452,14 +2503,21 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
             constexpr int NSTU = ((NLMAX * CWT + 1) * 64 + NTH - 1) / NTH;
             double* cur = lds;
             double* nxt = lds + (long)nat * 128;
-            const double* up[NSTU];
+            // Ut chunk staging: step g moves rows g NTH/4 .. of the chunk (4 pieces per row): a scalar base per step plus ONE
+            // per-thread offset (four 64-bit pointers before); threads beyond the chunk's last row re-read their step's first row
             d2 sg[NSTU];
-#pragma unroll
-            for (int g = 0; g < NSTU; ++g) {
-                const int e = (int)threadIdx.x + g * NTH;
-                up[g] = ut + (long)(e < nch ? e >> 2 : 0) * nop + ((e & 3) << 1);
-                sg[g] = *(const d2*)(up[g]);
-            }
+            const unsigned uvo = (unsigned)(((int)threadIdx.x >> 2) * (int)nop + (((int)threadIdx.x & 3) << 1)) * 8u;
+#define MRA_PRED_UT_LOADS(kcol) do { \
+_Pragma("unroll") \
+                for (int g = 0; g < NSTU; ++g) { \
+                    if (g * NTH < nch) { \
+                        const char* ub = (const char*)(ut + (long)(g * (NTH / 4)) * nop + (kcol)); \
+                        const unsigned vo = ((g + 1) * NTH <= nch || (int)threadIdx.x + g * NTH < nch) ? uvo : (unsigned)(((int)threadIdx.x & 3) << 4); \
+                        sg[g] = *(const d2*)(ub + vo); \
+                    } \
+                } \
+} while (0)
+            MRA_PRED_UT_LOADS(0);
             d2 xc = *(const d2*)tt;
 #pragma unroll
             for (int g = 0; g < NSTU; ++g) { const int e = (int)threadIdx.x + g * NTH; if (e < nch) *(d2*)(cur + 2 * e) = sg[g]; }
@@ -2496,8 +2554,7 @@ _Pragma("unroll") \
 #pragma nounroll
             for (int c = 0; c + 1 < nc; ++c) {
                 const int kn = (c + 1) * 8;
-#pragma unroll
-                for (int g = 0; g < NSTU; ++g) sg[g] = *(const d2*)(up[g] + kn);
+                MRA_PRED_UT_LOADS(kn);
                 const d2 xn = *(const d2*)(tt + kn);
                 MRA_PRED_UPD_CHUNK();
 #pragma unroll
@@ -2508,7 +2565,7 @@ _Pragma("unroll") \
             }
             // the deepest level's operands ride behind the last chunk (issued inside the loop, their address arithmetic
             // is hoisted out of it and spills)
-            MRA_PRED_STAGE_ISSUE_L(ar.nl - 1, ar.deep);
+            MRA_PRED_ISSUE_DEEP_A();
             pre_issued = true;
             MRA_PRED_UPD_CHUNK();
         }
@@ -2518,78 +2575,83 @@ _Pragma("unroll") \
     for (int mm = 0; mm < NLMAX; ++mm) {
         const int m = NLMAX - 1 - mm;
         if (m < ar.nl) {
-            const PredLevel lv = ar.lev[m];
-            const int slot = chain[m];
-            const int nzt = (m * CWT + 1) * CWT;            // Zt tiles: ancestors' tiles + the y tile, CWT k-tiles each
-            // ---- stage: Lt strictly-lower tiles, inverted diagonal blocks, Zt tiles [a][jb].  All of a
-            // thread's loads are issued together, and the loads of level m-1 are issued BEFORE the
-            // products of level m, so their L2 round trip (a load -> ds_write loop pays ~1 us per
-            // chunk, which was half of this kernel's run time) hides behind the MFMA work.
-            if (m == ar.nl - 1 && !pre_issued) MRA_PRED_STAGE_ISSUE(m);   // the first (deepest) level of this tree
-            __syncthreads();                                  // the previous level's products are done with the LDS image
-            {
-                const int total = (NTRI + CWT + nzt) * 128;
-#pragma unroll
-                for (int i = 0; i < PMAX; ++i) {
-                    if (i * NTH < total) {
-                        const int e = (int)threadIdx.x + i * NTH;
-                        if (e < total) *(d2*)(lds + 2 * e) = pre[i];
-                    }
-                }
-            }
+            const int SA = pred_sa<CWT, NLMAX, NTH>(m);      // tiles in half A; half B: the remaining TB tiles at tile offset offb
+            const int TB = pred_tiles_all<CWT>(m) - SA;
+            // ---- stage: all of a thread's loads of a half are issued together, and always BEFORE the products of the half in
+            // front of it, so their L2 round trip (a load -> ds_write loop pays ~1 us per chunk, which was half of this kernel's
+            // run time) hides behind MFMA work.
+            if (m == ar.nl - 1 && !pre_issued) MRA_PRED_ISSUE_RANGE(m, ar.lev[m], 0, SA);   // the first (deepest) level of this tree
+            __syncthreads();                                  // everybody is done with the previous level's LDS image (both halves)
+            MRA_PRED_WRITE_RANGE(0, SA);
+            if (TB > 0) MRA_PRED_ISSUE_RANGE(m, ar.lev[m], SA, TB);
+            else if (m > 0) MRA_PRED_ISSUE_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT, NLMAX, NTH>(m - 1)));
             __syncthreads();
-            if (m > 0) MRA_PRED_STAGE_ISSUE(m - 1);
             if (m < 5) MRA_PSTAMP(3 + 2 * m);
+            d4 x[CWT];                                        // MINUS X_m: every product below accumulates straight into its w tile (no separate accumulator: 8 registers)
+            // tile slot -> LDS address (slots below SA in half A, the others in half B)
+#define MRA_PRED_TILE(slot) (lds + (long)((slot) < SA ? (slot) : offb + (slot) - SA) * 256)
             if (active) {
-                d4 x[CWT];
 #pragma unroll
                 for (int jb = 0; jb < CWT; ++jb) {
                     d4 acc = w[m][jb];
-                    d4 upd = zero;
 #pragma unroll
                     for (int kb = 0; kb < CWT; ++kb) {
                         if (kb < jb) {
                             const d4 a = *(const d4*)(lds + (jb * (jb - 1) / 2 + kb) * 256 + prow * 16 + 4 * q);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) upd = mfma16(a[j], x[kb][j], upd);
+                            for (int j = 0; j < 4; ++j) acc = mfma16(a[j], x[kb][j], acc);
                         }
                     }
-                    acc -= upd;
                     const d4 ia = *(const d4*)(lds + (NTRI + jb) * 256 + prow * 16 + 4 * q);
                     d4 xx = zero;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xx = mfma16(ia[j], acc[j], xx);
-                    x[jb] = xx;
                     ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
+                    x[jb] = -xx;
                 }
-                // ancestors' tiles: front row block a = (m-1-k)*CWT + kt  (W columns are deepest level first)
+            }
+            // the row blocks of the front below the own block, in consumption order g = k CWT + kt (ancestor level k, tile kt), then y:
+            // those staged with half A now, the others after half B has landed
 #pragma unroll
-                for (int k = 0; k < NLMAX; ++k) {
-                    if (k < m) {
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1) {
+                    if (TB == 0) break;
+                    MRA_PRED_WRITE_RANGE(offb, TB);
+                    if (m > 0) MRA_PRED_ISSUE_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT, NLMAX, NTH>(m - 1)));
+                    __syncthreads();
+                }
+                if (active) {
 #pragma unroll
-                        for (int kt = 0; kt < CWT; ++kt) {
-                            const int a = (m - 1 - k) * CWT + kt;
-                            d4 acc = zero;
+                    for (int k = 0; k < NLMAX; ++k) {
+                        if (k < m) {
+#pragma unroll
+                            for (int kt = 0; kt < CWT; ++kt) {
+                                const int s0 = NTRI + CWT + (k * CWT + kt) * CWT;
+                                if ((s0 < SA) == (half == 0)) {
+#pragma unroll
+                                    for (int jb = 0; jb < CWT; ++jb) {
+                                        const d4 z = *(const d4*)(MRA_PRED_TILE(s0 + jb) + prow * 16 + 4 * q);
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) w[k][kt] = mfma16(z[j], x[jb][j], w[k][kt]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    {
+                        const int s0 = NTRI + CWT + m * CWT * CWT;      // the y row block follows the ancestors: its first row is Zt's y row
+                        if ((s0 < SA) == (half == 0)) {
 #pragma unroll
                             for (int jb = 0; jb < CWT; ++jb) {
-                                const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + prow * 16 + 4 * q);
+                                const d4 z = *(const d4*)(MRA_PRED_TILE(s0 + jb) + 4 * q);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc = mfma16(z[j], x[jb][j], acc);
+                                for (int j = 0; j < 4; ++j) yv = __builtin_fma(z[j], x[jb][j], yv);
                             }
-                            w[k][kt] -= acc;
                         }
                     }
                 }
-                {
-                    const int a = m * CWT;                   // the y tile follows the ancestors: its first row is Zt's y row
-#pragma unroll
-                    for (int jb = 0; jb < CWT; ++jb) {
-                        const d4 z = *(const d4*)(lds + (NTRI + CWT + a * CWT + jb) * 256 + 4 * q);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) yv = __builtin_fma(-z[j], x[jb][j], yv);
-                    }
-                }
             }
+#undef MRA_PRED_TILE
             if (m < 5) MRA_PSTAMP(4 + 2 * m);
         }
     }

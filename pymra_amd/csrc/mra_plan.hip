@@ -23,7 +23,21 @@ struct DevPool {
     std::multimap<std::pair<int, size_t>, void*> idle;                // (device, bytes) -> cached block
     size_t idle_bytes = 0;
     static constexpr size_t MIN_BLOCK = 256 * 1024;                   // smaller blocks are not worth keeping
-    static constexpr size_t MAX_IDLE = (size_t)64 << 30;              // cached bytes above this are returned to the driver
+    // Idle bytes above the cap go back to the driver at once (another runtime in the process - RCCL, a caller's torch - must not
+    // run out of memory while blocks sit here).  MRA_POOL_MAX_GB sets it (0 switches the cache off); the default is 16 GB or an
+    // eighth of the device's memory, whichever is smaller: four C3-sized plans, not a config-5 one (18 GB of W alone - an MLE
+    // loop at that size should keep its plan and call mra_plan_set_kernel, as bench.py does).
+    size_t max_idle() {
+        if (cap_known) return cap;
+        cap = (size_t)16 << 30;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 8 < cap) cap = tot / 8;
+        if (const char* e = getenv("MRA_POOL_MAX_GB")) { const double g = atof(e); cap = g > 0 ? (size_t)(g * (double)((size_t)1 << 30)) : 0; }
+        cap_known = true;
+        return cap;
+    }
+    size_t cap = 0;
+    bool cap_known = false;
     void flush_locked() {
         for (auto& e : idle) hipFree(e.second);
         idle.clear();
@@ -32,11 +46,20 @@ struct DevPool {
     ~DevPool() { /* process exit: the driver reclaims everything; calling into HIP from a static destructor is not safe */ }
 };
 DevPool g_pool;
+// MRA_POOL_POISON=1 (debug): every block handed out - fresh or reused - is filled with NaNs first, so that a buffer that relies on
+// zero-initialised or left-over contents shows up in the results (tests/test_gpu_parity.py runs the oracle parity cases once this way)
+inline bool pool_poison() { const char* e = getenv("MRA_POOL_POISON"); return e && e[0] && e[0] != '0'; }
+inline hipError_t poison_block(void* p, size_t n) {
+    if (!pool_poison() || !p || !n) return hipSuccess;
+    hipError_t e = hipMemset(p, 0xFF, n);                              // 0xFFFF...: a quiet NaN in every double, -1 in every int
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e;
+}
 }  // namespace
 
 hipError_t mraMalloc(void** p, size_t n) {
     if (g_dry) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-    if (n < DevPool::MIN_BLOCK) return hipMalloc(p, n);
+    if (n < DevPool::MIN_BLOCK) { hipError_t e = hipMalloc(p, n); return e == hipSuccess ? poison_block(*p, n) : e; }
     int dev = 0;
     hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_pool.mu);
@@ -46,7 +69,7 @@ hipError_t mraMalloc(void** p, size_t n) {
         g_pool.idle.erase(it);
         g_pool.idle_bytes -= n;
         g_pool.live[*p] = {dev, n};
-        return hipSuccess;
+        return poison_block(*p, n);
     }
     hipError_t e = hipMalloc(p, n);
     if (e != hipSuccess && !g_pool.idle.empty()) {                    // out of memory with blocks cached: give them back and retry
@@ -54,7 +77,7 @@ hipError_t mraMalloc(void** p, size_t n) {
         g_pool.flush_locked();
         e = hipMalloc(p, n);
     }
-    if (e == hipSuccess) g_pool.live[*p] = {dev, n};
+    if (e == hipSuccess) { g_pool.live[*p] = {dev, n}; e = poison_block(*p, n); }
     return e;
 }
 
@@ -66,7 +89,7 @@ hipError_t mraFree(void* p) {
     if (it == g_pool.live.end()) return hipFree(p);
     const std::pair<int, size_t> key = it->second;
     g_pool.live.erase(it);
-    if (g_pool.idle_bytes + key.second > DevPool::MAX_IDLE) return hipFree(p);
+    if (g_pool.idle_bytes + key.second > g_pool.max_idle()) return hipFree(p);
     g_pool.idle.insert({key, p});
     g_pool.idle_bytes += key.second;
     return hipSuccess;
@@ -1235,7 +1258,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
         pl->side_pending = false;
     }
     const bool fusedp = pl->regular && pl->use_fused && !pl->host_cov;
-    const bool hip_ = !fusedp && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
+    const bool hip_ = !fusedp && pl->regular_hi && pl->use_fused && !pl->host_cov;      // sharded plans too: the walk is per row tile, the fronts above the reduce level are complete by now
     if ((pl->run_flags & MRA_RUN_PREDICT) && fusedp) run_predict_fused(pl);
     if ((pl->run_flags & MRA_RUN_PREDICT) && hip_) run_predict_hi(pl);
     if ((pl->run_flags & MRA_RUN_PREDICT) && !fusedp && !hip_) {
@@ -1279,7 +1302,7 @@ static void finish_run(mra_plan* pl) {
             HIP_TRY(hipHostGetDevicePointer((void**)&pl->host_res_dev, pl->host_res, 0));
         }
         hipLaunchKernelGGL(k_sum_dnode, dim3(1), dim3(256), 0, pl->stream, pl->dnode.p, nsum, pl->host_res_dev, up, below, pl->errflag.p);
-        const bool hi_path = !(pl->regular && pl->use_fused && !pl->host_cov) && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
+        const bool hi_path = !(pl->regular && pl->use_fused && !pl->host_cov) && pl->regular_hi && pl->use_fused && !pl->host_cov;
         if ((pl->run_flags & MRA_RUN_PREDICT) && !(pl->regular && pl->use_fused && !pl->host_cov) && !hi_path)
             hipLaunchKernelGGL(k_extract_mean, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream,
                                pl->W.p, (long)pl->ldw, pl->Ka, pl->mean.p, pl->P);
@@ -1972,7 +1995,9 @@ int mra_get_timers(mra_plan* pl, double* out, int cap) {
 
 int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (!pl) return MRA_ERR_INVALID;
-    pl->cphantom_valid = false;
+    // options that change which kernel produces or factorises the leaves' C blocks bring the phantom-row launch back; the others
+    // (timing, front / knot / solve / update variants) never touch C
+    if (option == 2 || option == 3 || option == 6 || option == 11) pl->cphantom_valid = false;
     if (option == 1) { pl->ktiming = value != 0; return MRA_OK; }
     if (option == 2) { pl->use_fused = value != 0; return MRA_OK; }
     if (option == 3) { pl->gemm_lds = value != 0; return MRA_OK; }
@@ -2053,7 +2078,7 @@ int mra_plan_prepare(mra_plan* pl, int64_t* n_kernels) {
 int mra_get_kernel_stats(mra_plan* pl, int which, char* name, int name_cap, int* launches, double* ms, double* flops) {
     if (!pl || which < 0 || which >= KF_COUNT) return MRA_ERR_INVALID;
     const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
-    const bool hi_path = !fused && pl->regular_hi && pl->use_fused && !pl->host_cov && pl->reduce_level < 0;
+    const bool hi_path = !fused && pl->regular_hi && pl->use_fused && !pl->host_cov;
     if (name && name_cap > 0) { strncpy(name, kfam_name[fused ? 0 : (hi_path ? 2 : 1)][which], name_cap - 1); name[name_cap - 1] = 0; }
     if (launches) *launches = pl->kstat[which].launches;
     if (ms) *ms = pl->kstat[which].ms;

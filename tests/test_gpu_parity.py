@@ -509,6 +509,110 @@ def test_repeated_passes_are_bit_identical(hip):
     pl.close()
 
 
+def test_fused_path_with_leaves_above_128_observations(hip):
+    """Regular tree whose leaves hold 144 observations each (192 x 192 grid, r0 = 32, M = 4, every row observed: nine
+    observation tiles, more than the eight the fused row solve / predictive cascade take): those leaves go through the
+    12-tile row solve and the PLAIN update product (gLeafUpdatePlain + n_trsm_small) on the fused path.  A lost upload of
+    that descriptor array once faulted the GPU here while the suite stayed green (no other fused-path case has such
+    leaves).  Checked against the oracle, against the level-by-level kernels, and with the leaf-stage options in all
+    combinations, likelihood-only and predict passes back to back on one plan."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    np.random.seed(17)
+    n, r, M = 192, 32, 4
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y_obs = np.random.normal(size=(n * n, 1))                     # everything observed
+    topo = build_topology(locs, r, M, 4)
+    leaf_rows = (topo.node_row1 - topo.node_row0)[topo.node_leaf]
+    assert [int(v) for v in np.diff(topo.level_ptr)] == [4 ** k for k in range(M + 1)] and leaf_rows.min() >= 129 and leaf_rows.max() <= 192
+    spec = mt.KernelSpec(mt.KIND_MATERN32, 0.25, 1.2)
+    R = 2e-2
+    pl = hip.HipPlan(topo, 0); pl.set_locs(locs); pl.set_obs(y_obs, R); pl.set_kernel(spec.kind, spec.l, spec.sig, spec.scale)
+    pl.set_option(1, 1)
+    pl.run(True, True)
+    lik = sum(pl.likelihood())
+    mean, var = pl.predict()
+    ran = {k["name"]: k["launches"] for k in pl.kernel_stats()}
+    assert any("k_predict_cascade" in nm and c > 0 for nm, c in ran.items()), ran      # the fused path did run
+    pl.set_option(1, 0)
+    ref = run_levelwise(topo, locs, spec, y_obs, R)
+    assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-9 and K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+    for o7 in (0, 1, 2):
+        for o8 in (0, 1):
+            for o13 in (0, 1):
+                pl.set_option(7, o7); pl.set_option(8, o8); pl.set_option(13, o13)
+                pl.run(True, False)
+                assert abs(sum(pl.likelihood()) - lik) <= 1e-12 * abs(lik), (o7, o8, o13)
+                pl.run(True, True)
+                m2, v2 = pl.predict()
+                assert abs(sum(pl.likelihood()) - lik) <= 1e-12 * abs(lik), (o7, o8, o13)
+                assert np.max(np.abs(m2 - mean)) < 1e-10 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-9, (o7, o8, o13)
+    pl.set_option(7, 2); pl.set_option(8, 1); pl.set_option(13, 1); pl.set_option(2, 0)      # level-by-level kernels
+    pl.run(True, True)
+    m3, v3 = pl.predict()
+    assert abs(sum(pl.likelihood()) - lik) <= 1e-11 * abs(lik)
+    assert np.max(np.abs(m3 - mean)) < 1e-9 and K.rel(np.sqrt(v3), np.sqrt(var)) < 1e-8
+    pl.close()
+
+
+def test_chol_tiles_write_back_survives_repeated_passes(hip):
+    """k_chol_tiles factorises the leaves' C blocks in place and relies on the phantom observations' identity rows surviving
+    from pass to pass (they are written once, cphantom_valid).  Force that kernel (option 11 = 2) ONCE, then run predict /
+    likelihood-only / predict passes without touching any option in between: bit-identical results."""
+    cs = K.load_case("g64m")
+    pl, lik, mean, var = run_hip(hip, cs)
+    mean, var = mean.copy(), var.copy()
+    pl.set_option(11, 2)
+    pl.run(True, True)
+    lik_t = sum(pl.likelihood())
+    m_t, v_t = (a.copy() for a in pl.predict())
+    assert abs(lik_t - lik) <= 1e-12 * abs(lik) and np.max(np.abs(m_t - mean)) < 1e-11
+    for want_predict in (False, True, False, True):
+        pl.run(True, want_predict)
+        assert sum(pl.likelihood()) == lik_t
+        if want_predict:
+            m2, v2 = pl.predict()
+            assert np.array_equal(m2, m_t) and np.array_equal(v2, v_t)
+    pl.close()
+
+
+def test_no_buffer_relies_on_zero_initialised_memory(hip):
+    """The device-block cache hands the blocks of a destroyed plan to the next plan as they are.  With MRA_POOL_POISON=1 every
+    block the library hands out (fresh or reused, large or small) is filled with NaNs first: the oracle parity cases must come
+    out the same - fused path, general level-by-level path (1-D, irregular), sharded split run, likelihood-only first pass."""
+    import os
+    from oracle.mra_levelwise import run_levelwise
+    from pymra_amd.sharding import shard_topology
+    os.environ["MRA_POOL_POISON"] = "1"
+    try:
+        for name in ("g32", "c1", "u3", "g64m", "t201"):
+            cs = K.load_case(name)
+            ref = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+            for first_predict in (False, True):
+                pl = hip.HipPlan(cs["topo"], 0)
+                pl.set_locs(cs["locs"]); pl.set_obs(cs["y_obs"], cs["c"]["R"])
+                s = cs["spec"]
+                pl.set_kernel(s.kind, s.l, s.sig, s.scale)
+                pl.run(True, first_predict)
+                assert abs(sum(pl.likelihood()) - ref["lik"]) <= 1e-10 * abs(ref["lik"]), (name, first_predict)
+                pl.run(True, True)
+                mean, var = pl.predict()
+                own = cs["topo"].perm[cs["topo"].in_leaf]
+                assert np.max(np.abs(mean[own] - ref["mean"][own])) < 1e-9, name
+                assert K.rel(np.sqrt(var[own]), ref["sd"][own]) < 1e-8, name
+                pl.close()
+        cs = K.load_case("g64m")
+        ref = run_levelwise(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+        liks, mean, var, _ = K.emulate_world_on_one_gpu(hip, cs["topo"], cs["locs"], cs["y_obs"], cs["c"]["R"], cs["spec"], 8)
+        assert max(abs(l - ref["lik"]) for l in liks) <= 1e-10 * abs(ref["lik"])
+        assert np.max(np.abs(mean - ref["mean"])) < 1e-9 and K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+    finally:
+        del os.environ["MRA_POOL_POISON"]
+        hip.release_cached_memory()
+
+
 def test_root_view_attributes(hip):
     import pymra_amd
     import pymra_amd.MRATools as mt

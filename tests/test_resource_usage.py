@@ -1,7 +1,9 @@
 """Register / scratch budget of the kernels in the product build ("a kernel-resource report with no scratch
 is part of done").  __graft_entry__.build() compiles every translation unit with -Rpass-analysis=kernel-resource-usage and keeps
 the remarks of that very build next to the library (pymra_amd/libmra_hip.resource_usage.txt); this test parses them - no
-second compile - and fails when a kernel that a C3 / C5 pass launches uses scratch memory, or when any other kernel starts to.
+second compile - and fails when a kernel that a C3 / C5 pass launches (one GPU or a shard) uses scratch memory, or when any
+other kernel starts to.  Exceptions among the production kernels are PINNED (exact byte counts: growth fails the test, and so
+does an improvement that forgets to delete the entry): k_parent_front<12>.
 
 ALLOWED lists the known exceptions with their bound and the reason; anything else must report 0 bytes of scratch."""
 import os
@@ -21,6 +23,13 @@ PRODUCTION = [
     r"k_chol_wave<12>", r"k_trsm_rows2<8>", r"k_trsm_rows2<12>", r"k_front<true>", r"k_leaf_solve_update<8, 13, true>",
     r"k_gemm_nt_lds<2, 2, 0>", r"k_gemm_nt_lds<1, 2, 0>", r"k_gemm_nt<0, 2, 0>", r"k_gemm_nt<1, 2, 0>", r"k_panel_chol",
     r"k_trsm_rows2<4>", r"k_front<false>", r"k_sum_dnode", r"k_leaf_cphantom", r"k_assemble", r"k_leaf_moments",
+    # shards (at most two leaves per CU) and config 5
+    r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
+    r"k_predict_cascade<2, 6, 4, true, 3>", r"k_predict_cascade<2, 6, 4, false, 3>", r"k_predict_cascade<4, 4, 8, false, 1>",
+]
+# production kernels with a known, pinned amount of scratch: (pattern, exact bytes per lane)
+PINNED = [
+    (r"k_parent_front<12>", 36),                          # around chol16_inv, once per workgroup, outside the K loop
 ]
 # (pattern, max scratch bytes per lane, reason)
 ALLOWED = [
@@ -33,7 +42,6 @@ ALLOWED = [
     # dominant kernel at three workgroups per CU (168 registers): the staging registers of the NEXT level's operands are parked
     # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
     # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
-    (r"k_predict_cascade<2, 6, 4, (true|false), 3>", 96, "level-operand staging parked across the level barrier"),
     (r"k_predict_cascade<2, 8, 8, (true|false), 1>", 72, "eight row tiles per workgroup at 7-8 levels: not launched (cascade_wpw = 4)"),
     # the diagonal-block routine (chol16_inv, ~100 registers) runs beside 96 accumulator registers; the spills sit around it,
     # once per workgroup, outside the K loop
@@ -66,6 +74,14 @@ def test_production_kernels_use_no_scratch(usage):
         assert hits, "kernel %s not found in the remarks" % pat
         for n, r in hits.items():
             assert r["scratch"] == 0, "%s: %d B/lane of scratch, %s spilled registers" % (n, r["scratch"], r["spills"])
+
+
+def test_pinned_exceptions_are_exact(usage):
+    for pat, nbytes in PINNED:
+        hits = _find(usage, pat)
+        assert hits, "kernel %s not found in the remarks" % pat
+        for n, r in hits.items():
+            assert r["scratch"] == nbytes, "%s: %d B/lane of scratch, pinned at %d" % (n, r["scratch"], nbytes)
 
 
 def test_no_other_kernel_starts_to_spill(usage):
