@@ -143,6 +143,12 @@ class _Recursion:
             Bs = [self.B_rows(a, rp) for a in chain]
             s.A = [[Bs[k].T @ HRinvH @ Bs[l] for l in range(m + 1)] for k in range(m + 1)]
             s.omg = [Bs[k].T @ HRinvObs for k in range(m + 1)]
+        elif not kids:
+            # a non-leaf node without children: only on PRUNED trees (a rank's local tree keeps every upper node but only its
+            # own subtrees, pymra_amd.sharding); the sums over children are empty
+            rk = [self.rank_of(a) for a in chain]
+            s.A = [[np.zeros((rk[k], rk[l])) for l in range(m + 1)] for k in range(m + 1)]
+            s.omg = [np.zeros(rk[k]) for k in range(m + 1)]
         else:
             s.A = [[sum(st[c].ATil[k][l] for c in kids) for l in range(m + 1)] for k in range(m + 1)]
             s.omg = [sum(st[c].omgTil[k] for c in kids) for k in range(m + 1)]

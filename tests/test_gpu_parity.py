@@ -6,7 +6,8 @@ level-wise oracle (same algorithm) the HIP path is held to 1e-10 / 1e-9; against
 own numbers it is held to 1e-9 (lik), 1e-7 (mean) and 1e-6 (sd, ExpCovFun).  For Matern32 the
 REFERENCE's sd is itself only good to ~1e-3 relative (explicit inverses + eigh square root,
 SURVEY.md section 7 hard part 5; adjudicated in extended precision by tests/test_oracle_extended.py),
-so there the 1e-6 bar is applied against the oracle and the golden sd is checked to 2e-3.
+so there the 1e-6 bar is applied against the oracle AND against 80-bit runs of the same model (1e-9), and the golden sd is
+checked to the reference's own measured error per case (c1 1e-7, g64m 1e-5, g128m 1e-3; C3 at full size 5e-5).
 """
 import numpy as np
 import pytest
@@ -52,7 +53,20 @@ def test_hip_matches_oracle_and_reference_goldens(hip, name):
     if not hard:
         assert abs(lik - g["lik"]) <= 1e-9 * abs(g["lik"])
         assert np.max(np.abs(mean - g["mean"])) < 1e-7
-        assert K.rel(sd, g["sd"]) < (1e-6 if cs["c"]["kern"] == "exp" else 2e-3)
+        # sd against the reference: ExpCovFun goldens are good to ~1e-8; the reference's Matern32 sd carries its own error
+        # (explicit inverses + eigh square root, pyMRA/MRANode.py:444-445, 504-507), measured against 80-bit runs in
+        # tests/test_oracle_extended.py: c1 < 1e-8, g64m < 1e-5, g128m 6.6e-4 - so the bound is per case, and the HIP sd is held
+        # to the 80-bit truth itself below
+        ref_sd_bound = {"c1": 1e-7, "g64m": 1e-5, "g128m": 1e-3}
+        assert K.rel(sd, g["sd"]) < (1e-6 if cs["c"]["kern"] == "exp" else ref_sd_bound[name])
+    if cs["c"]["kern"] == "m32" and name in ("c1", "g64m", "g128m"):
+        from oracle.mra_extended import run_extended
+        ext = run_extended(cs["topo"], cs["locs"], cs["spec"], cs["y_obs"], cs["c"]["R"])
+        assert K.rel(sd, ext["sd"]) < 1e-9 and np.max(np.abs(mean - ext["mean"])) < 1e-9      # north_star: 1e-6
+        if name == "g128m":
+            e_ref = np.abs(g["sd"] - ext["sd"]) / ext["sd"]
+            e_us = np.abs(sd - g["sd"]) / ext["sd"]
+            assert np.max(np.abs(e_us - e_ref)) < 1e-8       # we differ from the reference exactly where it differs from the truth
     pl.close()
 
 

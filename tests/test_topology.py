@@ -5,7 +5,7 @@ import pytest
 import _cases as K
 
 
-@pytest.mark.parametrize("name", [n for n in K.SMALL + K.MEDIUM + K.LARGE if K.have(n)])
+@pytest.mark.parametrize("name", [n for n in K.SMALL + K.MEDIUM + K.LARGE + K.HEADLINE if K.have(n)])
 def test_topology_matches_reference(name):
     cs = K.load_case(name)
     g, topo = cs["g"], cs["topo"]
