@@ -32,21 +32,39 @@ namespace mra_topo {
 struct MT19937 {
     uint32_t* key;
     int pos;
+    // (written as three plain loops over distinct index ranges with the conditional as a mask, so that the compiler vectorises
+    //  them: the first 227 words read old words 397 ahead, the rest read new words 227 behind - dependence distances far above
+    //  any vector width)
     inline void regenerate() {
         const uint32_t MATRIX_A = 0x9908b0dfU, UPPER = 0x80000000U, LOWER = 0x7fffffffU;
-        int kk;
-        uint32_t y;
-        for (kk = 0; kk < 624 - 397; ++kk) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+        uint32_t* const k = key;
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int kk = 0; kk < 624 - 397; ++kk) {
+            const uint32_t y = (k[kk] & UPPER) | (k[kk + 1] & LOWER);
+            k[kk] = k[kk + 397] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
         }
-        for (; kk < 623; ++kk) {
-            y = (key[kk] & UPPER) | (key[kk + 1] & LOWER);
-            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int kk = 624 - 397; kk < 623; ++kk) {
+            const uint32_t y = (k[kk] & UPPER) | (k[kk + 1] & LOWER);
+            k[kk] = k[kk - (624 - 397)] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
         }
-        y = (key[623] & UPPER) | (key[0] & LOWER);
-        key[623] = key[396] ^ (y >> 1) ^ ((y & 1U) ? MATRIX_A : 0U);
+        const uint32_t y = (k[623] & UPPER) | (k[0] & LOWER);
+        k[623] = k[396] ^ (y >> 1) ^ ((0U - (y & 1U)) & MATRIX_A);
         pos = 0;
+    }
+    // n tempered outputs (n <= 624 - pos) straight from the state, vectorisable
+    inline void temper_out(uint32_t* __restrict__ out, int n) {
+        const uint32_t* __restrict__ k = key + pos;
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int i = 0; i < n; ++i) {
+            uint32_t y = k[i];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680U;
+            y ^= (y << 15) & 0xefc60000U;
+            y ^= (y >> 18);
+            out[i] = y;
+        }
+        pos += n;
     }
     inline uint32_t next32() {
         if (pos == 624) regenerate();
@@ -101,7 +119,12 @@ struct MTStream {
                 uint32_t* out = ring.data() + (size_t)(b % NBLOCK) * BLOCK;
                 for (int i = 0; i < 624; ++i) snap[(size_t)(b % NBLOCK) * 624 + i] = key[i];
                 snap_pos[b % NBLOCK] = gen.pos;
-                for (int i = 0; i < BLOCK; ++i) out[i] = gen.next32();
+                for (int i = 0; i < BLOCK;) {
+                    if (gen.pos == 624) gen.regenerate();
+                    const int n = std::min(624 - gen.pos, BLOCK - i);
+                    gen.temper_out(out + i, n);
+                    i += n;
+                }
                 ++b;
                 produced.store(b, std::memory_order_release);
             }
@@ -163,6 +186,37 @@ struct MTStream {
             }
         }
     }
+    // The targets v_i = interval(i) of steps i = i_hi .. i_lo, into vs[i] (same words, same rejection rule as shuffle_stores; a
+    // rejected word writes vs[i], the accepted one overwrites it).  No random access at all: the consumer resolves the shuffle
+    // backwards from these (replay_quadtree).  On return i = i_lo - 1.
+    inline void draw_targets(uint32_t* vs, int64_t& i, int64_t i_lo) {
+        while (i >= i_lo) {
+            uint64_t mask = (uint64_t)i;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+            const int64_t lo = std::max<int64_t>(i_lo, (int64_t)(mask >> 1) + 1);
+            const uint32_t m32 = (uint32_t)mask;
+            while (i >= lo) {
+                if (cur_i == BLOCK) {
+                    if (cur_block >= 0) released.store(cur_block + 1, std::memory_order_release);
+                    ++cur_block;
+                    while (produced.load(std::memory_order_acquire) <= cur_block) std::this_thread::yield();
+                    cur = ring.data() + (size_t)(cur_block % NBLOCK) * BLOCK;
+                    cur_i = 0;
+                }
+                const uint32_t* w = cur + cur_i;
+                const int nw = BLOCK - cur_i;
+                int k = 0;
+                int64_t ii = i;
+                for (; k < nw && ii >= lo; ++k) {
+                    const uint32_t v = w[k] & m32;
+                    vs[ii] = v;
+                    ii -= (int64_t)v <= ii;
+                }
+                cur_i += k;
+                i = ii;
+            }
+        }
+    }
     // generator state after exactly the words handed out so far
     void final_state(uint32_t* key_out, int32_t* pos_out) {
         stop.store(true, std::memory_order_release);
@@ -175,6 +229,25 @@ struct MTStream {
         for (int i = 0; i < cur_i; ++i) (void)g.next32();
         for (int i = 0; i < 624; ++i) key_out[i] = k2[i];
         *pos_out = g.pos;
+    }
+};
+
+// sense-reversing barrier for a small team of threads that meet every few hundred microseconds (spin, then yield)
+struct SpinBarrier {
+    const int n;
+    std::atomic<int> count{0};
+    std::atomic<int> sense{0};
+    explicit SpinBarrier(int n_) : n(n_) {}
+    void wait() {
+        if (n <= 1) return;
+        const int s0 = sense.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1) {
+            count.store(0, std::memory_order_relaxed);
+            sense.store(s0 ^ 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (sense.load(std::memory_order_acquire) == s0) { if (++spins > 2000) std::this_thread::yield(); }
+        }
     }
 };
 
@@ -196,7 +269,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     const bool trace = getenv("MRA_TRACE_REPLAY") != nullptr;         // phase times on stderr (tools/e2e_breakdown.py)
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    double t_cand = 0, t_shuf = 0;
+    double t_cand = 0, t_shuf = 0, t_gen = 0;
     // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the
     //      row order so every pass is a sequential sweep
     // Work arrays live in a process-wide scratch area that only grows: a fresh 100 MB of vectors per call costs more in page
@@ -208,6 +281,8 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         std::vector<double> cur, nxt_xy;
         std::vector<uint8_t> code, used;
         std::vector<int32_t> leaf_of, perm_idx;
+        std::vector<uint32_t> vs;
+        std::vector<uint64_t> bits;
         std::vector<int64_t> leaf_off, pos_of;
     };
     static Scratch ws;
@@ -231,36 +306,95 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     int n_thr = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("MRA_HOST_THREADS")) n_thr = std::max(1, atoi(e));
     int failed = 0;
-    for (int m = 0; m < M; ++m) {
-        const std::vector<int32_t>& ord = orders[m];
-        const std::vector<int64_t>& st = starts[m];
-        const int64_t nn = (int64_t)st.size() - 1;
-        orders[m + 1].resize(N);
-        starts[m + 1].assign(4 * nn + 1, 0);
-        std::vector<int32_t>& nxt = orders[m + 1];
-        std::vector<int64_t>& nst = starts[m + 1];
-        // the nodes of a level are independent (each one's mean is still one sequential accumulation, as np.mean does it):
-        // contiguous node ranges of about equal row counts go to a few threads
-        std::atomic<int> bad{0};
-        auto work = [&](int64_t j0, int64_t j1) {
-            for (int64_t j = j0; j < j1; ++j) {
-                const int64_t s = st[j], e = st[j + 1], n = e - s;
-                if (n <= 100) { bad.store(1); return; }
-                double sx = 0.0, sy = 0.0;                       // np.mean(axis=0): sequential accumulation, then / n
-                for (int64_t t = s; t < e; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
-                const double mx = sx / (double)n, my = sy / (double)n;
+    // One team of threads walks all levels together (SPMD with spin barriers: spawning threads per level and phase costs more
+    // than a deep level does).  Per level: (A) the means - one sequential accumulation per node, as np.mean does it, nodes dealt
+    // to the threads; (B) quadrant codes and counts per WORK ITEM, an item being a node or, on the upper levels where a level
+    // has fewer nodes than the team has threads, a slice of a node (the root alone is the whole first pass: a single thread
+    // spent as long on it as on the four deepest levels together); (C) one thread turns the counts into the children's start
+    // offsets per item - stable: ascending caller index inside every child -; (D) the scatter.
+    struct Item { int64_t node, s, e; int64_t off[4]; };
+    std::vector<Item> items;
+    std::vector<double> mean_xy;
+    std::vector<int64_t> item_thr;                       // first item of every thread
+    SpinBarrier bar(n_thr);
+    std::atomic<int> bad{0};
+    auto team = [&](int tid) {
+        for (int m = 0; m < M; ++m) {
+            const std::vector<int32_t>& ord = orders[m];
+            const std::vector<int64_t>& st = starts[m];
+            const int64_t nn = (int64_t)st.size() - 1;
+            if (tid == 0) {
+                orders[m + 1].resize(N);
+                starts[m + 1].assign(4 * nn + 1, 0);
+                mean_xy.assign(2 * nn, 0.0);
+                // work items: about four per thread on the upper levels, whole nodes below
+                items.clear();
+                const int64_t target = std::max<int64_t>(4096, N / (4 * (int64_t)n_thr));
+                for (int64_t j = 0; j < nn; ++j) {
+                    const int64_t s0 = st[j], e0 = st[j + 1], n = e0 - s0;
+                    if (n <= 100) bad.store(1);
+                    const int64_t nc = std::max<int64_t>(1, n / target);
+                    for (int64_t c = 0; c < nc; ++c) items.push_back(Item{j, s0 + n * c / nc, s0 + n * (c + 1) / nc, {0, 0, 0, 0}});
+                }
+                item_thr.assign(n_thr + 1, (int64_t)items.size());
+                item_thr[0] = 0;
+                size_t k = 0;
+                for (int t = 1; t < n_thr; ++t) {           // contiguous runs of items of about equal row counts
+                    const int64_t goal = (N * t) / n_thr;
+                    while (k < items.size() && items[k].s < goal) ++k;
+                    item_thr[t] = (int64_t)k;
+                }
+            }
+            bar.wait();
+            if (bad.load()) return;
+            std::vector<int32_t>& nxt = orders[m + 1];
+            std::vector<int64_t>& nst = starts[m + 1];
+            // (A) np.mean(axis=0): sequential accumulation, then / n
+            for (int64_t j = tid; j < nn; j += n_thr) {
+                const int64_t s0 = st[j], e0 = st[j + 1];
+                double sx = 0.0, sy = 0.0;
+                for (int64_t t = s0; t < e0; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
+                mean_xy[2 * j] = sx / (double)(e0 - s0);
+                mean_xy[2 * j + 1] = sy / (double)(e0 - s0);
+            }
+            bar.wait();
+            // (B)
+            for (int64_t k = item_thr[tid]; k < item_thr[tid + 1]; ++k) {
+                Item& it = items[k];
+                const double mx = mean_xy[2 * it.node], my = mean_xy[2 * it.node + 1];
                 int64_t cnt[4] = {0, 0, 0, 0};
-                for (int64_t t = s; t < e; ++t) {
+                for (int64_t t = it.s; t < it.e; ++t) {
                     const uint8_t c = (uint8_t)(2 * (cur[2 * t] > mx) + (cur[2 * t + 1] > my));
                     code[t] = c;
                     ++cnt[c];
                 }
-                if (!cnt[0] || !cnt[1] || !cnt[2] || !cnt[3]) { bad.store(1); return; }
-                int64_t off[4];
-                off[0] = s; off[1] = off[0] + cnt[0]; off[2] = off[1] + cnt[1]; off[3] = off[2] + cnt[2];
-                for (int c = 0; c < 4; ++c) nst[4 * j + c] = off[c];
-                int32_t* const inv_next = (m + 1 < M) ? inv[m + 1].data() : nullptr;
-                for (int64_t t = s; t < e; ++t) {                 // stable: ascending caller index inside every child
+                for (int c = 0; c < 4; ++c) it.off[c] = cnt[c];
+            }
+            bar.wait();
+            // (C)
+            if (tid == 0) {
+                size_t k = 0;
+                for (int64_t j = 0; j < nn; ++j) {
+                    const size_t k0 = k;
+                    int64_t tot[4] = {0, 0, 0, 0};
+                    for (; k < items.size() && items[k].node == j; ++k) for (int c = 0; c < 4; ++c) tot[c] += items[k].off[c];
+                    if (!tot[0] || !tot[1] || !tot[2] || !tot[3]) { bad.store(1); break; }
+                    int64_t run[4];
+                    run[0] = st[j]; run[1] = run[0] + tot[0]; run[2] = run[1] + tot[1]; run[3] = run[2] + tot[2];
+                    for (int c = 0; c < 4; ++c) nst[4 * j + c] = run[c];
+                    for (size_t q = k0; q < k; ++q) for (int c = 0; c < 4; ++c) { const int64_t n = items[q].off[c]; items[q].off[c] = run[c]; run[c] += n; }
+                }
+                nst[4 * nn] = N;
+            }
+            bar.wait();
+            if (bad.load()) return;
+            // (D) stable scatter
+            int32_t* const inv_next = (m + 1 < M) ? inv[m + 1].data() : nullptr;
+            for (int64_t k = item_thr[tid]; k < item_thr[tid + 1]; ++k) {
+                Item& it = items[k];
+                int64_t off[4] = {it.off[0], it.off[1], it.off[2], it.off[3]};
+                const int64_t j = it.node;
+                for (int64_t t = it.s; t < it.e; ++t) {
                     const int64_t d = off[code[t]]++;
                     const int32_t x = ord[t];
                     nxt[d] = x;
@@ -270,26 +404,18 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                     else leaf_of[x] = (int32_t)(4 * j + code[t]);
                 }
             }
-        };
-        const int T = (int)std::min<int64_t>(n_thr, nn);
-        if (T <= 1) work(0, nn);
-        else {
-            std::vector<std::thread> pool;
-            int64_t j0 = 0;
-            for (int t = 0; t < T; ++t) {
-                int64_t j1 = j0;
-                const int64_t goal = (N * (t + 1)) / T;
-                while (j1 < nn && (st[j1 + 1] <= goal || j1 == j0)) ++j1;
-                if (t == T - 1) j1 = nn;
-                pool.emplace_back(work, j0, j1);
-                j0 = j1;
-            }
-            for (auto& th : pool) th.join();
+            bar.wait();
+            if (tid == 0) cur.swap(nxt_xy);
+            bar.wait();
         }
-        if (bad.load()) { failed = 1; break; }
-        nst[4 * nn] = N;
-        cur.swap(nxt_xy);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(team, t);
+        team(0);
+        for (auto& th : pool) th.join();
     }
+    if (bad.load()) failed = 1;
     if (failed) return 1;
     const double t_part = now();
     // ---- the part of the flat layout that does not depend on the knots, on a helper thread beside the knot draws
@@ -299,13 +425,14 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     leaf_off.assign(nleaf + 1, 0);
     pos_of.resize(N);                                    // every caller row sits in exactly one leaf: all entries are written below
     const std::vector<int32_t>& oM = orders[M];
+    // (sizes and allocations here, not in the helper thread: an allocation failure there would end the process)
+    for (int64_t l = 0; l < nleaf; ++l) {
+        const int64_t c = starts[M][l + 1] - starts[M][l];
+        leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
+    }
+    out.P = leaf_off[nleaf];
+    if (!out.ext_perm) { out.perm.resize(out.P); out.src.resize(out.P); out.in_leaf.resize(out.P); }
     std::thread layout([&]() {
-        for (int64_t l = 0; l < nleaf; ++l) {
-            const int64_t c = starts[M][l + 1] - starts[M][l];
-            leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
-        }
-        out.P = leaf_off[nleaf];
-        if (!out.ext_perm) { out.perm.resize(out.P); out.src.resize(out.P); out.in_leaf.resize(out.P); }
         int64_t* const perm_o = out.ext_perm ? out.ext_perm : out.perm.data();
         int64_t* const src_o = out.ext_perm ? out.ext_src : out.src.data();
         uint8_t* const inl_o = out.ext_perm ? out.ext_in_leaf : out.in_leaf.data();
@@ -319,7 +446,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{layout};
     // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
     MTStream rng(mt_key, *mt_pos);
-    auto& used = ws.used; auto& knots = ws.knots; auto& perm_idx = ws.perm_idx;
+    auto& used = ws.used; auto& knots = ws.knots; auto& perm_idx = ws.perm_idx; auto& vs = ws.vs; auto& bits = ws.bits;
     used.assign(N, 0);
     if ((int)knots.size() < M) knots.resize(M);                // per level: r knots per node, node-major
     for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
@@ -346,18 +473,47 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         std::sort(upos.begin(), upos.end());
         const int64_t nc = (e - s) - (int64_t)upos.size();        // candidates = rows of the node not used by an ancestor
         if (nc <= min_cand) return 1;
-        perm_idx.resize(nc);
-        for (int64_t i = 0; i < nc; ++i) perm_idx[i] = (int32_t)i;
         const double tc1 = trace ? now() : 0.0;
-        // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[interval(i)], and the knots are p[0 .. r-1].
-        // Position i is never touched again after step i (later steps pick targets <= their own i), so for i >= r only the
-        // store p[k] = p[i] matters: one sequential read and one random STORE per step - no random load, nothing to wait for
-        // (with the full swap every step was a cache miss on the upper levels, whose arrays of 10^5 - 10^6 entries exceed the cache)
+        // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[v_i], v_i = interval(i), and the knots are p[0 .. r-1].
+        // Position i is never touched again after step i, so for i >= r only the move p[v_i] = p[i] matters - and of all those
+        // moves only the few that end up in p[0 .. r-1].  Resolved BACKWARDS: slot k < r wants the content of position k; the
+        // LAST move into a wanted position w is the step with the smallest i >= r and v_i = w, and it carried what position i held
+        // then - so the slot now wants position i, and the search goes on among the steps above i.  One ascending sweep over the
+        // targets with a bitmap of the (at most r) wanted positions does it for all slots at once: a sequential read and one
+        // bit test per step (the map of the root is 128 KB), against a random 4-byte store into a 4 MB array per step before.
+        // The targets themselves come off the generator's word stream in the generator's order (steps n-1 .. r), branch-free.
         {
+            const int64_t rr = (int64_t)std::max<int32_t>(r, 1);
+            vs.resize((size_t)nc + 8);
             int64_t i = nc - 1;
+            rng.draw_targets(vs.data(), i, rr);                               // steps i = nc-1 .. r
+            if (trace) t_gen += now() - tc1;
+            const size_t nwords = ((size_t)nc + 63) / 64;
+            bits.assign(nwords, 0);
+            perm_idx.resize(rr);
+            for (int64_t k = 0; k < rr && k < nc; ++k) { perm_idx[k] = (int32_t)k; bits[k >> 6] |= (uint64_t)1 << (k & 63); }
+            const uint32_t* const v = vs.data();
+            uint64_t* const bm = bits.data();
+            int32_t* const want = perm_idx.data();
+            auto hit = [&](int64_t ii) {
+                const uint32_t t = v[ii];
+                if (!((bm[t >> 6] >> (t & 63)) & 1)) return;
+                int k = 0;
+                while (want[k] != (int32_t)t) ++k;                            // a set bit always has its slot
+                want[k] = (int32_t)ii;
+                bm[t >> 6] &= ~((uint64_t)1 << (t & 63));
+                bm[ii >> 6] |= (uint64_t)1 << (ii & 63);
+            };
+            int64_t ii = rr;
+            for (; ii + 4 <= nc; ii += 4) {
+                const uint32_t a = v[ii], b = v[ii + 1], c = v[ii + 2], d = v[ii + 3];
+                const uint64_t any = ((bm[a >> 6] >> (a & 63)) | (bm[b >> 6] >> (b & 63)) | (bm[c >> 6] >> (c & 63)) | (bm[d >> 6] >> (d & 63))) & 1;
+                if (any) { hit(ii); hit(ii + 1); hit(ii + 2); hit(ii + 3); }  // in order: a move may be into the position just taken up
+            }
+            for (; ii < nc; ++ii) hit(ii);
+            // p[0 .. r-1] now: the original (= identity) content of the wanted positions; the last r-1 steps are plain swaps
             int32_t* const pp = perm_idx.data();
-            rng.shuffle_stores(pp, i, (int64_t)std::max<int32_t>(r, 1));        // steps i = nc-1 .. r
-            for (; i >= 1; --i) std::swap(pp[i], pp[rng.interval((uint64_t)i)]);
+            for (i = rr - 1; i >= 1; --i) std::swap(pp[i], pp[rng.interval((uint64_t)i)]);
         }
         // the r picks are indices into the candidate list (ascending row order): map the k-th candidate to its row by stepping
         // over the ancestors' knots; the reference re-sorts the knots into location order (MRANode.py:203-204) = ascending pick
@@ -437,8 +593,8 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     }
     const double t_nodes = now();
     rng.final_state(mt_key, mt_pos);
-    if (trace) fprintf(stderr, "replay_quadtree N=%lld: partition %.1f ms, knots %.1f ms (candidates %.1f, shuffles %.1f), layout join %.1f ms, node arrays %.1f ms, rng state %.1f ms\n",
-                       (long long)N, t_part - t_begin, t_knots - t_part, t_cand, t_shuf, t_join - t_knots, t_nodes - t_join, now() - t_nodes);
+    if (trace) fprintf(stderr, "replay_quadtree N=%lld: partition %.1f ms, knots %.1f ms (candidates %.1f, shuffles %.1f of which target draws %.1f), layout join %.1f ms, node arrays %.1f ms, rng state %.1f ms\n",
+                       (long long)N, t_part - t_begin, t_knots - t_part, t_cand, t_shuf, t_gen, t_join - t_knots, t_nodes - t_join, now() - t_nodes);
     return 0;
 }
 
