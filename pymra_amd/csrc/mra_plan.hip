@@ -10,8 +10,22 @@
 // DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
 #include "mra_plan_types.h"
 #include "mra_topology.h"
+#include <chrono>
 #include <mutex>
 #include <thread>
+
+// MRA_TRACE_PLAN=1: host-side phase times of plan construction on stderr (tools/e2e_breakdown.py)
+namespace {
+struct PlanTrace {
+    bool on;
+    double t0, last;
+    const char* what;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit PlanTrace(const char* w) : on(getenv("MRA_TRACE_PLAN") != nullptr), t0(now()), last(t0), what(w) {}
+    void mark(const char* label) { if (on) { const double t = now(); fprintf(stderr, "  [%s] %-34s %7.2f ms\n", what, label, t - last); last = t; } }
+    ~PlanTrace() { if (on) fprintf(stderr, "  [%s] total %.2f ms\n", what, now() - t0); }
+};
+}  // namespace
 
 // ---- device memory cache --------------------------------------------------------------------------------------------
 #include <map>
@@ -118,6 +132,7 @@ static int fail(mra_plan* p, const MraError& e) {
 
 // ------------------------------------------------------------------------------------------------
 static void build_static(mra_plan* pl) {
+    PlanTrace tr("build_static");
     const int L = pl->n_levels;
     pl->Ka = 0;
     for (int m = 0; m < L; ++m) {
@@ -164,6 +179,7 @@ static void build_static(mra_plan* pl) {
     HIP_TRY(mraMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
     HIP_TRY(mraMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
     pl->knots_dev.upload(pl->knot_rows);
+    tr.mark("checks, allocations, memsets");
 
     // knot index arrays for the gather side of the prior GEMM (padded to cw with -1)
     std::vector<int> kidx;
@@ -206,6 +222,7 @@ static void build_static(mra_plan* pl) {
         lv.F.alloc(nn * (size_t)lv.nf * lv.ldf + 16);
         lv.invF.alloc(nn * (size_t)lv.cwt * 256);
     }
+    tr.mark("knot_idx, level buffers");
     // leaves
     pl->leaf_nodes.clear();
     pl->leaf_slot.assign(pl->n_nodes, -1);
@@ -238,6 +255,7 @@ static void build_static(mra_plan* pl) {
     // so the per-leaf Schur blocks Gt (146 GB at 2048^2, M=8, r0=64) are only allocated on demand (ensure_gt)
     if (!pl->shape_regular) pl->Gt.alloc(pl->leaf_goff.back());
 
+    tr.mark("leaf maps (row_leaf upload)");
     // descriptors that do not depend on the observations
     std::vector<AsmChild> kids;
     pl->kid_leaf.clear();
@@ -338,6 +356,7 @@ static void build_static(mra_plan* pl) {
     }
     pl->asmKids.upload(kids);
     pl->hKids = kids;
+    tr.mark("per-level descriptors");
 
     // ---- fused path eligibility: uniform block width on all non-leaf levels, leaves only on the last level
     pl->regular = false;
@@ -486,6 +505,7 @@ static void build_static(mra_plan* pl) {
                                  + (size_t)nlv * cwt * 16 * (pl->d + 1) * sizeof(double);    // + the chain's knots (coordinates, real/phantom flags)
             pl->knot_chain_ok = pl->knot_chain_lds <= 160 * 1024;
         }
+        tr.mark("fused levels, knot chain");
         std::vector<long> r0s, fwg0, lwg0;
         std::vector<int> chains, fwgn, tleaf, lwgn;
         {
@@ -551,11 +571,13 @@ static void build_static(mra_plan* pl) {
             pl->cascade_stage_all = pl->cascade_lds_all <= 160 * 1024;
             pl->ft_wg0_leaf.upload(lwg0); pl->ft_wgn_leaf.upload(lwgn); pl->n_fwg_leaf = (long)lwg0.size();
         }
+        tr.mark("row tiles of the cascades");
     }
 }
 
 // leaf descriptors: depend on which rows are observed
 static void build_leaf(mra_plan* pl, const double* y) {
+    PlanTrace tr("build_leaf");
     const size_t nl = pl->leaf_nodes.size();
     pl->cphantom_valid = false;
     pl->leaf_nop.assign(nl, 0);
@@ -585,8 +607,10 @@ static void build_leaf(mra_plan* pl, const double* y) {
     }
     obs_off[nl] = (long)obs.size();
     pl->obs_idx.upload(obs); pl->obs_pos.upload(opos); pl->leaf_nobs.upload(nobs);
+    tr.mark("observation lists");
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
+    tr.mark("panel allocation");
     std::vector<LeafProb> lp(nl);
     std::vector<GemmProb> gr(nl), gs(nl), gu(nl), grl(nl);
     std::vector<PanelProb> pf(nl), pk(nl), pc(nl);
@@ -649,6 +673,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         gu[t] = u;
         pl->fl_leaf_update += Work(2.0 * nr * nat * no, 2.0 * nr * na * nop, 8.0 * ((double)nr * nop + (double)na * nop + 2.0 * nr * na));
     }
+    tr.mark("leaf descriptors (host)");
     {
         std::vector<double*> uts(nl);
         for (size_t t = 0; t < nl; ++t) uts[t] = pl->panel.p + pl->leaf_poff[t] + (size_t)pl->leaf_nop[t] * pl->leaf_nop[t];
@@ -657,6 +682,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         // the Ut blocks start from zero: rows of the y block beyond y itself and phantom observation columns stay zero
         if (pl->panel.n) HIP_TRY(mraMemset(pl->panel.p, 0, pl->panel.n * sizeof(double)));
     }
+    tr.mark("panel memset");
     pl->parent_syrk = false;
     pl->hLeafSyrk = gs;
     if (pl->shape_regular && pl->NL >= 1) {
@@ -768,6 +794,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
             if (pl->parent_front_lds > 160 * 1024 || lv.panel_only) pl->parent_front_nacc = 0;
         }
     }
+    tr.mark("parent / grandparent descriptors");
     pl->hLeafResid = gr; pl->leaf_nobs_host = nobs;
     pl->gLeafResidLik.upload(grl);
     pl->gLeaf.upload(lp); pl->gLeafResid.upload(gr); pl->gLeafSyrk.upload(gs); pl->gLeafUpdate.upload(gu);
@@ -1661,6 +1688,7 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
             HIP_TRY(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         }
         for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
+        { PlanTrace tr("mra_plan_create"); tr.mark("copies of the topology, streams, events"); }
         build_static(pl);
         *out = pl;
         return MRA_OK;
@@ -1752,36 +1780,49 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
 int mra_plan_set_locs_rows(mra_plan* pl, const double* locs, const int64_t* src) {
     if (!pl || !locs || !src) return MRA_ERR_INVALID;
     try {
+        PlanTrace tr("set_locs_rows");
         std::lock_guard<std::mutex> lock(g_stage_mutex);
         const int d = pl->d;
         double* xp = stage_buffer((size_t)pl->P * d);
+        tr.mark("staging buffer");
         parallel_rows(pl->P, [&](int64_t a, int64_t b) {
             if (d == 2) for (int64_t p = a; p < b; ++p) { const int64_t q = src[p]; xp[2 * p] = locs[2 * q]; xp[2 * p + 1] = locs[2 * q + 1]; }
             else for (int64_t p = a; p < b; ++p) xp[p] = locs[src[p]];
         });
-        return mra_plan_set_locs(pl, xp);
+        tr.mark("gather into leaf order");
+        const int rc = mra_plan_set_locs(pl, xp);
+        tr.mark("upload X, knot coordinates");
+        return rc;
     } catch (const MraError& e) { return fail(pl, e); }
 }
 
 int mra_plan_set_obs_rows(mra_plan* pl, const double* y, const int64_t* src, const int64_t* perm, double R) {
     if (!pl || !y || !src || !perm) return MRA_ERR_INVALID;
     try {
+        PlanTrace tr("set_obs_rows");
         std::lock_guard<std::mutex> lock(g_stage_mutex);
         double* yp = stage_buffer((size_t)pl->P);
         const double nan = std::nan("");
         parallel_rows(pl->P, [&](int64_t a, int64_t b) { for (int64_t p = a; p < b; ++p) yp[p] = perm[p] < 0 ? nan : y[src[p]]; });
-        return mra_plan_set_obs(pl, yp, R);
+        tr.mark("gather into leaf order");
+        const int rc = mra_plan_set_obs(pl, yp, R);
+        tr.mark("upload y, build_leaf");
+        return rc;
     } catch (const MraError& e) { return fail(pl, e); }
 }
 
 int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_leaf, int64_t N, double* mean, double* var) {
     if (!pl || !perm || !in_leaf || !mean || !var || N <= 0) return MRA_ERR_INVALID;
     try {
+        PlanTrace tr("get_predict_rows");
         std::lock_guard<std::mutex> lock(g_stage_mutex);
         double* st = stage_buffer((size_t)pl->P * 2);
+        tr.mark("staging buffer");
         const int rc = mra_get_predict(pl, st, st + pl->P);
         if (rc != MRA_OK) return rc;
+        tr.mark("D2H mean, var");
         parallel_rows(N, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { mean[i] = 0.0; var[i] = 0.0; } });
+        tr.mark("zero the caller's arrays");
         const double* mp = st; const double* vp = st + pl->P;
         // every caller row sits in exactly one padded row, so the scatter has no write conflicts between threads
         parallel_rows(pl->P, [&](int64_t a, int64_t b) {

@@ -263,99 +263,158 @@ struct Result {
     std::vector<int32_t> parent, child_ptr, child_list, level, preorder, cw;
 };
 
+// Process-wide scratch area of the replay (grow-only: a fresh 100 MB of vectors per call costs more in page faults and unmapping -
+// 10 + 10 ms at 1024^2 - than a partition level does, and MLE loops replay the same tree size again and again: README.md:96-104
+// builds a new MRATree per objective call).  One replay at a time; release_scratch() gives the memory back
+// (mra_release_cached_memory).
+struct Scratch {
+    std::vector<std::vector<int32_t>> orders, inv;
+    std::vector<std::vector<int64_t>> starts, knots;
+    std::vector<double> cur, nxt_xy;
+    std::vector<uint8_t> code, used;
+    std::vector<int32_t> leaf_of, perm_idx;
+    std::vector<uint32_t> vs;
+    std::vector<uint64_t> bits;
+    std::vector<int64_t> leaf_off, pos_of;
+};
+inline Scratch& scratch() { static Scratch ws; return ws; }
+inline std::mutex& scratch_mutex() { static std::mutex m; return m; }
+inline void release_scratch() {
+    std::lock_guard<std::mutex> lock(scratch_mutex());
+    scratch() = Scratch();
+}
+
+// Called (on a helper thread, while the knot draws are still running on the caller's thread) as soon as everything that does not
+// depend on the knots is final: P, perm / src / in_leaf, the node arrays with knot_ptr of the NON-leaf nodes (r knots each: rows
+// 0 .. n_nonleaf r of knot_rows; the leaves' entries and all of knot_rows follow when replay_quadtree returns).  A plan can be
+// sized, allocated and fed its locations and observations from this (mra_plan_create_replay_2d).  Must not throw.
+typedef void (*LayoutHook)(void* user, const struct Result& partial);
+
 // returns 0 on success, 1 if the tree does not follow the large-2-D rules (nothing modified)
-inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out) {
+inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos, Result& out,
+                           LayoutHook hook = nullptr, void* hook_user = nullptr) {
     if (M < 1 || N <= 0 || r <= 0 || N >= 0x7fffffffLL) return 1;
     const bool trace = getenv("MRA_TRACE_REPLAY") != nullptr;         // phase times on stderr (tools/e2e_breakdown.py)
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    double t_cand = 0, t_shuf = 0, t_gen = 0;
-    // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the
-    //      row order so every pass is a sequential sweep
-    // Work arrays live in a process-wide scratch area that only grows: a fresh 100 MB of vectors per call costs more in page
-    // faults and unmapping (10 + 10 ms at 1024^2) than a partition level does, and MLE loops replay the same tree size again
-    // and again (README.md:96-104 builds a new MRATree per objective call).  One replay at a time.
-    struct Scratch {
-        std::vector<std::vector<int32_t>> orders, inv;
-        std::vector<std::vector<int64_t>> starts, knots;
-        std::vector<double> cur, nxt_xy;
-        std::vector<uint8_t> code, used;
-        std::vector<int32_t> leaf_of, perm_idx;
-        std::vector<uint32_t> vs;
-        std::vector<uint64_t> bits;
-        std::vector<int64_t> leaf_off, pos_of;
-    };
-    static Scratch ws;
-    static std::mutex ws_mutex;
-    std::lock_guard<std::mutex> ws_lock(ws_mutex);
-    auto& orders = ws.orders; auto& starts = ws.starts;
+    double t_cand = 0, t_shuf = 0, t_gen = 0, t_wait = 0;
+    std::lock_guard<std::mutex> ws_lock(scratch_mutex());
+    Scratch& ws = scratch();
+    // ---- all allocations up front, on this thread (a failure inside a helper thread would end the process)
+    const int L = M + 1;
+    const int64_t nleaf = (int64_t)1 << (2 * M);
+    auto& orders = ws.orders; auto& starts = ws.starts; auto& inv = ws.inv; auto& leaf_of = ws.leaf_of;
+    auto& cur = ws.cur; auto& nxt_xy = ws.nxt_xy; auto& code = ws.code;
+    auto& leaf_off = ws.leaf_off; auto& pos_of = ws.pos_of;
+    auto& used = ws.used; auto& knots = ws.knots; auto& perm_idx = ws.perm_idx; auto& vs = ws.vs; auto& bits = ws.bits;
     if ((int)orders.size() < M + 1) orders.resize(M + 1);
     if ((int)starts.size() < M + 1) starts.resize(M + 1);
-    orders[0].resize(N);
-    for (int64_t i = 0; i < N; ++i) orders[0][i] = (int32_t)i;
-    starts[0] = {0, N};
-    auto& cur = ws.cur; auto& nxt_xy = ws.nxt_xy; auto& code = ws.code;
+    if ((int)inv.size() < M) inv.resize(std::max(M, 1));
+    for (int m = 0; m <= M; ++m) { orders[m].resize(N); starts[m].assign(((int64_t)1 << (2 * m)) + 1, 0); }
+    for (int m = 1; m < M; ++m) inv[m].resize(N);           // inv[m][x] = position of caller row x in orders[m] (level 0 is the identity)
+    leaf_of.resize(N);                                     // leaf_of[x] = the leaf of caller row x
     cur.resize(2 * N); nxt_xy.resize(2 * N); code.resize(N);
+    leaf_off.assign(nleaf + 1, 0);
+    pos_of.resize(N);
+    used.assign(N, 0);
+    if ((int)knots.size() < M) knots.resize(M);                // per level: r knots per node, node-major
+    for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
+    vs.resize((size_t)N + 8);
+    bits.resize(((size_t)N + 63) / 64);
+    const int64_t cap_rows = N + 15 * nleaf;
+    if (!out.ext_perm) { out.perm.resize(cap_rows); out.src.resize(cap_rows); out.in_leaf.resize(cap_rows); }
+    if (!out.ext_knot_rows) out.knot_rows.resize(N);          // every caller row is the knot of exactly one node (leaves take what is left)
+    out.n_levels = L;
+    out.level_ptr.assign(L + 1, 0);
+    for (int m = 0; m < L; ++m) out.level_ptr[m + 1] = out.level_ptr[m] + ((int64_t)1 << (2 * m));
+    const int64_t nn_all = out.level_ptr[L];
+    out.n_nodes = (int32_t)nn_all;
+    out.level.assign(nn_all, 0); out.row0.assign(nn_all, 0); out.row1.assign(nn_all, 0); out.leaf.assign(nn_all, 0);
+    out.parent.assign(nn_all, -1); out.child_ptr.assign(nn_all + 1, 0);
+    out.child_list.assign(4 * (size_t)out.level_ptr[M], 0);
+    out.knot_ptr.assign(nn_all + 1, 0);
+    out.cw.assign(L, 0);
+    out.preorder.assign(nn_all, 0);
+    std::vector<int32_t> upos;
+    upos.reserve((size_t)r * (size_t)std::max(M, 1));
+    std::vector<int64_t> picks(r);
+    std::vector<std::pair<int, int64_t>> stack;
+    stack.reserve(4 * (size_t)M + 8);
+
+    for (int64_t i = 0; i < N; ++i) orders[0][i] = (int32_t)i;
+    starts[0][0] = 0; starts[0][1] = N;
     memcpy(cur.data(), xy, (size_t)2 * N * sizeof(double));
-    // inv[m][x] = position of caller row x in orders[m] (levels 1 .. M-1; level 0 is the identity), leaf_of[x] = its leaf:
-    // written by the partition threads, they let the knot phase find "the k-th not-yet-used row of a node" without scanning the node
-    auto& inv = ws.inv; auto& leaf_of = ws.leaf_of;
-    if ((int)inv.size() < M) inv.resize(M);
-    for (int m = 1; m < M; ++m) inv[m].resize(N);
-    leaf_of.resize(N);
+
     int n_thr = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("MRA_HOST_THREADS")) n_thr = std::max(1, atoi(e));
-    int failed = 0;
-    // One team of threads walks all levels together (SPMD with spin barriers: spawning threads per level and phase costs more
-    // than a deep level does).  Per level: (A) the means - one sequential accumulation per node, as np.mean does it, nodes dealt
-    // to the threads; (B) quadrant codes and counts per WORK ITEM, an item being a node or, on the upper levels where a level
-    // has fewer nodes than the team has threads, a slice of a node (the root alone is the whole first pass: a single thread
-    // spent as long on it as on the four deepest levels together); (C) one thread turns the counts into the children's start
-    // offsets per item - stable: ascending caller index inside every child -; (D) the scatter.
+    // the partition team runs BESIDE the knot draws (which only ever need the levels at and above the node they are at): two
+    // hardware threads stay with the draws and the generator
+    const int n_team = std::max(1, n_thr - 2);
+
+    // ---- partitions of all levels (they do not depend on the knots); the coordinates travel with the row order so every pass
+    // is a sequential sweep.  One team of threads walks all levels together (SPMD with spin barriers: spawning threads per level
+    // and phase costs more than a deep level does).  Per level: (A) the means - one sequential accumulation per node, as np.mean
+    // does it (bit for bit: rows that sit exactly on a mean change child otherwise), nodes dealt to the threads; (B) quadrant
+    // codes and counts per WORK ITEM, an item being a node or, on the upper levels where a level has fewer nodes than the team
+    // has threads, a slice of a node (the root alone is the whole first pass); (C) one thread turns the counts into the
+    // children's start offsets per item - stable: ascending caller index inside every child -; (D) the scatter.
     struct Item { int64_t node, s, e; int64_t off[4]; };
     std::vector<Item> items;
-    std::vector<double> mean_xy;
-    std::vector<int64_t> item_thr;                       // first item of every thread
-    SpinBarrier bar(n_thr);
+    items.reserve((size_t)nleaf + 64 * (size_t)n_team);
+    std::vector<double> mean_xy((size_t)2 * (size_t)nleaf, 0.0);
+    std::vector<int64_t> item_thr((size_t)n_team + 1, 0);
+    SpinBarrier bar(n_team);
     std::atomic<int> bad{0};
+    // The knot draws go depth first (the reference's RNG order), so the partition does, too, at the grain of the four level-1
+    // subtrees: the root, then all levels of subtree 0, then subtree 1, ... - the draws of subtree q run while the team partitions
+    // subtree q + 1.  progress[q] = m: levels <= m of orders / starts / inv are final inside level-1 subtree q.
+    struct Pass { int m; int64_t j0, j1; int q; };
+    std::vector<Pass> passes;
+    passes.push_back(Pass{0, 0, 1, -1});
+    for (int q = 0; q < 4; ++q)
+        for (int m = 1; m < M; ++m) passes.push_back(Pass{m, (int64_t)q << (2 * (m - 1)), (int64_t)(q + 1) << (2 * (m - 1)), q});
+    std::atomic<int> progress[4];
+    for (int q = 0; q < 4; ++q) progress[q].store(0);
+    for (int m = 0; m <= M; ++m) starts[m][(size_t)1 << (2 * m)] = N;
     auto team = [&](int tid) {
-        for (int m = 0; m < M; ++m) {
+        for (size_t ip = 0; ip < passes.size(); ++ip) {
+            const Pass ps = passes[ip];
+            const int m = ps.m;
             const std::vector<int32_t>& ord = orders[m];
             const std::vector<int64_t>& st = starts[m];
-            const int64_t nn = (int64_t)st.size() - 1;
+            std::vector<int32_t>& nxt = orders[m + 1];
+            std::vector<int64_t>& nst = starts[m + 1];
+            const double* const cxy = (m & 1) ? nxt_xy.data() : cur.data();       // the coordinate arrays swap roles every level
+            double* const nxy = (m & 1) ? cur.data() : nxt_xy.data();
+            const int64_t row_lo = st[ps.j0], row_hi = st[ps.j1], rows = row_hi - row_lo;
             if (tid == 0) {
-                orders[m + 1].resize(N);
-                starts[m + 1].assign(4 * nn + 1, 0);
-                mean_xy.assign(2 * nn, 0.0);
                 // work items: about four per thread on the upper levels, whole nodes below
                 items.clear();
-                const int64_t target = std::max<int64_t>(4096, N / (4 * (int64_t)n_thr));
-                for (int64_t j = 0; j < nn; ++j) {
+                const int64_t target = std::max<int64_t>(4096, rows / (4 * (int64_t)n_team));
+                for (int64_t j = ps.j0; j < ps.j1; ++j) {
                     const int64_t s0 = st[j], e0 = st[j + 1], n = e0 - s0;
                     if (n <= 100) bad.store(1);
                     const int64_t nc = std::max<int64_t>(1, n / target);
                     for (int64_t c = 0; c < nc; ++c) items.push_back(Item{j, s0 + n * c / nc, s0 + n * (c + 1) / nc, {0, 0, 0, 0}});
                 }
-                item_thr.assign(n_thr + 1, (int64_t)items.size());
+                item_thr.assign((size_t)n_team + 1, (int64_t)items.size());
                 item_thr[0] = 0;
                 size_t k = 0;
-                for (int t = 1; t < n_thr; ++t) {           // contiguous runs of items of about equal row counts
-                    const int64_t goal = (N * t) / n_thr;
+                for (int t = 1; t < n_team; ++t) {           // contiguous runs of items of about equal row counts
+                    const int64_t goal = row_lo + (rows * t) / n_team;
                     while (k < items.size() && items[k].s < goal) ++k;
                     item_thr[t] = (int64_t)k;
                 }
             }
             bar.wait();
             if (bad.load()) return;
-            std::vector<int32_t>& nxt = orders[m + 1];
-            std::vector<int64_t>& nst = starts[m + 1];
-            // (A) np.mean(axis=0): sequential accumulation, then / n
-            for (int64_t j = tid; j < nn; j += n_thr) {
-                const int64_t s0 = st[j], e0 = st[j + 1];
-                double sx = 0.0, sy = 0.0;
-                for (int64_t t = s0; t < e0; ++t) { sx += cur[2 * t]; sy += cur[2 * t + 1]; }
-                mean_xy[2 * j] = sx / (double)(e0 - s0);
-                mean_xy[2 * j + 1] = sy / (double)(e0 - s0);
+            // (A) np.mean(axis=0): sequential accumulation, then / n; the two coordinates are independent sums
+            for (int64_t w = 2 * ps.j0 + tid; w < 2 * ps.j1; w += n_team) {
+                const int64_t j = w >> 1, s0 = st[j], e0 = st[j + 1];
+                const double* cc = cxy + (w & 1);
+                double sx = 0.0;
+                for (int64_t t = s0; t < e0; ++t) sx += cc[2 * t];
+                mean_xy[w] = sx / (double)(e0 - s0);
             }
             bar.wait();
             // (B)
@@ -364,7 +423,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                 const double mx = mean_xy[2 * it.node], my = mean_xy[2 * it.node + 1];
                 int64_t cnt[4] = {0, 0, 0, 0};
                 for (int64_t t = it.s; t < it.e; ++t) {
-                    const uint8_t c = (uint8_t)(2 * (cur[2 * t] > mx) + (cur[2 * t + 1] > my));
+                    const uint8_t c = (uint8_t)(2 * (cxy[2 * t] > mx) + (cxy[2 * t + 1] > my));
                     code[t] = c;
                     ++cnt[c];
                 }
@@ -374,7 +433,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             // (C)
             if (tid == 0) {
                 size_t k = 0;
-                for (int64_t j = 0; j < nn; ++j) {
+                for (int64_t j = ps.j0; j < ps.j1; ++j) {
                     const size_t k0 = k;
                     int64_t tot[4] = {0, 0, 0, 0};
                     for (; k < items.size() && items[k].node == j; ++k) for (int c = 0; c < 4; ++c) tot[c] += items[k].off[c];
@@ -382,9 +441,9 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                     int64_t run[4];
                     run[0] = st[j]; run[1] = run[0] + tot[0]; run[2] = run[1] + tot[1]; run[3] = run[2] + tot[2];
                     for (int c = 0; c < 4; ++c) nst[4 * j + c] = run[c];
+                    nst[4 * j + 4] = st[j + 1];            // (the next node writes the same value; its pass may come much later)
                     for (size_t q = k0; q < k; ++q) for (int c = 0; c < 4; ++c) { const int64_t n = items[q].off[c]; items[q].off[c] = run[c]; run[c] += n; }
                 }
-                nst[4 * nn] = N;
             }
             bar.wait();
             if (bad.load()) return;
@@ -398,41 +457,29 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                     const int64_t d = off[code[t]]++;
                     const int32_t x = ord[t];
                     nxt[d] = x;
-                    nxt_xy[2 * d] = cur[2 * t];
-                    nxt_xy[2 * d + 1] = cur[2 * t + 1];
+                    nxy[2 * d] = cxy[2 * t];
+                    nxy[2 * d + 1] = cxy[2 * t + 1];
                     if (inv_next) inv_next[x] = (int32_t)d;
                     else leaf_of[x] = (int32_t)(4 * j + code[t]);
                 }
             }
             bar.wait();
-            if (tid == 0) cur.swap(nxt_xy);
-            bar.wait();
+            if (tid == 0) {
+                if (ps.q < 0) for (int q = 0; q < 4; ++q) progress[q].store(1, std::memory_order_release);
+                else progress[ps.q].store(m + 1, std::memory_order_release);
+            }
         }
     };
-    {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < n_thr; ++t) pool.emplace_back(team, t);
-        team(0);
-        for (auto& th : pool) th.join();
-    }
-    if (bad.load()) failed = 1;
-    if (failed) return 1;
-    const double t_part = now();
-    // ---- the part of the flat layout that does not depend on the knots, on a helper thread beside the knot draws
-    const int L = M + 1;
-    const int64_t nleaf = (int64_t)1 << (2 * M);
-    auto& leaf_off = ws.leaf_off; auto& pos_of = ws.pos_of;
-    leaf_off.assign(nleaf + 1, 0);
-    pos_of.resize(N);                                    // every caller row sits in exactly one leaf: all entries are written below
+    // ---- the flat layout that does not depend on the knots, on the partition's thread 0 right behind the last level
     const std::vector<int32_t>& oM = orders[M];
-    // (sizes and allocations here, not in the helper thread: an allocation failure there would end the process)
-    for (int64_t l = 0; l < nleaf; ++l) {
-        const int64_t c = starts[M][l + 1] - starts[M][l];
-        leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
-    }
-    out.P = leaf_off[nleaf];
-    if (!out.ext_perm) { out.perm.resize(out.P); out.src.resize(out.P); out.in_leaf.resize(out.P); }
-    std::thread layout([&]() {
+    double t_part = 0, t_layout = 0;
+    std::atomic<int> layout_done{0};
+    auto layout = [&]() {
+        for (int64_t l = 0; l < nleaf; ++l) {
+            const int64_t c = starts[M][l + 1] - starts[M][l];
+            leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
+        }
+        out.P = leaf_off[nleaf];
         int64_t* const perm_o = out.ext_perm ? out.ext_perm : out.perm.data();
         int64_t* const src_o = out.ext_perm ? out.ext_src : out.src.data();
         uint8_t* const inl_o = out.ext_perm ? out.ext_in_leaf : out.in_leaf.data();
@@ -442,37 +489,95 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
             for (int64_t t = s; t < e; ++t, ++p) { perm_o[p] = oM[t]; src_o[p] = oM[t]; inl_o[p] = 1; pos_of[oM[t]] = p; }
             for (; p < leaf_off[l + 1]; ++p) { perm_o[p] = -1; src_o[p] = oM[s]; inl_o[p] = 0; }      // phantom rows copy the leaf's first location
         }
-    });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{layout};
-    // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each
+        // node arrays (knot_ptr: the non-leaf nodes' r knots each; the leaves' entries follow with the knots)
+        size_t nchild = 0;
+        for (int m = 0; m < L; ++m) {
+            const int64_t span = (int64_t)1 << (2 * (M - m));
+            for (int64_t j = 0; j < ((int64_t)1 << (2 * m)); ++j) {
+                const int64_t i = out.level_ptr[m] + j;
+                out.level[i] = m;
+                out.row0[i] = leaf_off[j * span];
+                out.row1[i] = leaf_off[(j + 1) * span];
+                out.leaf[i] = (m == M);
+                out.parent[i] = m ? (int32_t)(out.level_ptr[m - 1] + j / 4) : -1;
+                if (m < M) for (int c = 0; c < 4; ++c) out.child_list[nchild++] = (int32_t)(out.level_ptr[m + 1] + 4 * j + c);
+                out.child_ptr[i + 1] = (int32_t)nchild;
+                out.knot_ptr[i + 1] = m < M ? (i + 1) * (int64_t)r : out.knot_ptr[i];      // (leaves: provisional, empty)
+            }
+        }
+        for (int m = 0; m < M; ++m) out.cw[m] = (r + 15) / 16 * 16;
+        {
+            size_t np = 0;
+            std::vector<int64_t> st2;
+            st2.reserve(4 * (size_t)L + 8);
+            st2.push_back(0);
+            while (!st2.empty()) {
+                const int64_t i = st2.back();
+                st2.pop_back();
+                out.preorder[np++] = (int32_t)i;
+                if (!out.leaf[i]) {
+                    const int m = out.level[i];
+                    const int64_t c0 = out.level_ptr[m + 1] + 4 * (i - out.level_ptr[m]);
+                    for (int c = 3; c >= 0; --c) st2.push_back(c0 + c);
+                }
+            }
+        }
+        if (hook) hook(hook_user, out);
+    };
+    std::vector<std::thread> pool;
+    struct Joiner { std::vector<std::thread>& p; ~Joiner() { for (auto& t : p) if (t.joinable()) t.join(); } } joiner{pool};
+    for (int t = 0; t < n_team; ++t)
+        pool.emplace_back([&, t]() {
+            team(t);
+            if (t == 0) {
+                t_part = now();
+                if (!bad.load()) layout();
+                t_layout = now();
+                layout_done.store(1, std::memory_order_release);
+            }
+        });
+    // ---- knots: depth-first pre-order, one shuffle of arange(n_cand) each; a node of level m needs levels <= m of the partition
     MTStream rng(mt_key, *mt_pos);
-    auto& used = ws.used; auto& knots = ws.knots; auto& perm_idx = ws.perm_idx; auto& vs = ws.vs; auto& bits = ws.bits;
-    used.assign(N, 0);
-    if ((int)knots.size() < M) knots.resize(M);                // per level: r knots per node, node-major
-    for (int m = 0; m < M; ++m) knots[m].assign(((int64_t)1 << (2 * m)) * r, -1);
-    std::vector<int32_t> upos;
-    std::vector<int64_t> picks(r);
-    std::vector<std::pair<int, int64_t>> stack;
     stack.push_back({0, 0});
     const int64_t min_cand = std::max<int64_t>(100, std::max<int64_t>(r, 4));
+    int failed = 0;
     while (!stack.empty()) {
         const int m = stack.back().first;
         const int64_t j = stack.back().second;
         stack.pop_back();
+        if (m >= 1) {
+            std::atomic<int>& pq = progress[j >> (2 * (m - 1))];
+            if (pq.load(std::memory_order_acquire) < m) {
+                const double tw0 = trace ? now() : 0.0;
+                int spins = 0;
+                while (pq.load(std::memory_order_acquire) < m && !bad.load()) { if (++spins > 200) std::this_thread::yield(); }
+                if (trace) t_wait += now() - tw0;
+            }
+        }
+        if (bad.load()) { failed = 1; break; }
         const int64_t s = starts[m][j], e = starts[m][j + 1];
         const double tc0 = trace ? now() : 0.0;
-        // positions (inside this node's row order) of the rows its ancestors took as knots: at most r per ancestor
+        // positions (inside this node's row order) of the rows its ancestors took as knots: at most r per ancestor.  A knot of the
+        // level-k ancestor is followed down the path to this node: inv[l][x] is final for a row x of the level-(l-1) ancestor (that
+        // node has been partitioned), and only for those - the partition of the other subtrees may still be running, and what
+        // inv holds there is left over from the previous tree
         upos.clear();
         for (int k = 0; k < m; ++k) {
             const int64_t* ak = knots[k].data() + (j >> (2 * (m - k))) * r;
             for (int i = 0; i < r; ++i) {
                 const int64_t x = ak[i];
-                if (((int64_t)leaf_of[x] >> (2 * (M - m))) == j) upos.push_back((int32_t)(inv[m][x] - s));     // m >= 1 here
+                int64_t p = -1;
+                for (int l = k + 1; l <= m; ++l) {
+                    const int64_t a = j >> (2 * (m - l));                      // this node's ancestor on level l (itself for l = m)
+                    p = inv[l][x];
+                    if (p < starts[l][a] || p >= starts[l][a + 1]) { p = -1; break; }
+                }
+                if (p >= 0) upos.push_back((int32_t)(p - s));
             }
         }
         std::sort(upos.begin(), upos.end());
         const int64_t nc = (e - s) - (int64_t)upos.size();        // candidates = rows of the node not used by an ancestor
-        if (nc <= min_cand) return 1;
+        if (nc <= min_cand) { failed = 1; break; }
         const double tc1 = trace ? now() : 0.0;
         // RandomState.shuffle (_shuffle_raw): for i = n-1 .. 1 swap p[i] with p[v_i], v_i = interval(i), and the knots are p[0 .. r-1].
         // Position i is never touched again after step i, so for i >= r only the move p[v_i] = p[i] matters - and of all those
@@ -484,12 +589,11 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         // The targets themselves come off the generator's word stream in the generator's order (steps n-1 .. r), branch-free.
         {
             const int64_t rr = (int64_t)std::max<int32_t>(r, 1);
-            vs.resize((size_t)nc + 8);
             int64_t i = nc - 1;
             rng.draw_targets(vs.data(), i, rr);                               // steps i = nc-1 .. r
             if (trace) t_gen += now() - tc1;
             const size_t nwords = ((size_t)nc + 63) / 64;
-            bits.assign(nwords, 0);
+            std::fill(bits.begin(), bits.begin() + nwords, (uint64_t)0);
             perm_idx.resize(rr);
             for (int64_t k = 0; k < rr && k < nc; ++k) { perm_idx[k] = (int32_t)k; bits[k >> 6] |= (uint64_t)1 << (k & 63); }
             const uint32_t* const v = vs.data();
@@ -533,68 +637,33 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
         for (int i = 0; i < r; ++i) used[kn[i]] = 1;
         if (m + 1 < M) for (int c = 3; c >= 0; --c) stack.push_back({m + 1, 4 * j + c});
     }
-    // ---- flat layout: node arrays and knot rows (needs the knots and the helper thread's row positions)
     const double t_knots = now();
-    layout.join();
+    // ---- join the partition / layout (and the hook), then the knot rows
+    for (auto& t : pool) if (t.joinable()) t.join();
     const double t_join = now();
-    out.n_levels = L;
-    out.level_ptr.assign(L + 1, 0);
-    for (int m = 0; m < L; ++m) out.level_ptr[m + 1] = out.level_ptr[m] + ((int64_t)1 << (2 * m));
-    const int64_t nn = out.level_ptr[L];
-    out.n_nodes = (int32_t)nn;
-    out.level.assign(nn, 0); out.row0.assign(nn, 0); out.row1.assign(nn, 0); out.leaf.assign(nn, 0);
-    out.parent.assign(nn, -1); out.child_ptr.assign(nn + 1, 0);
-    out.child_list.clear();
-    out.knot_ptr.assign(nn + 1, 0);
-    out.knot_rows.clear();
-    if (!out.ext_knot_rows) out.knot_rows.resize(N);          // every caller row is the knot of exactly one node (leaves take what is left)
+    if (failed || bad.load()) return 1;
     int64_t* const kr_o = out.ext_knot_rows ? out.ext_knot_rows : out.knot_rows.data();
     int64_t nkr = 0;
     for (int m = 0; m < L; ++m) {
-        const int64_t span = (int64_t)1 << (2 * (M - m));
         for (int64_t j = 0; j < ((int64_t)1 << (2 * m)); ++j) {
             const int64_t i = out.level_ptr[m] + j;
-            out.level[i] = m;
-            out.row0[i] = leaf_off[j * span];
-            out.row1[i] = leaf_off[(j + 1) * span];
-            out.leaf[i] = (m == M);
-            out.parent[i] = m ? (int32_t)(out.level_ptr[m - 1] + j / 4) : -1;
             if (m < M) {
-                for (int c = 0; c < 4; ++c) out.child_list.push_back((int32_t)(out.level_ptr[m + 1] + 4 * j + c));
                 const int64_t* kn = knots[m].data() + j * r;
                 for (int t = 0; t < r; ++t) kr_o[nkr++] = pos_of[kn[t]];
             } else {
                 const int64_t s = starts[M][j], e = starts[M][j + 1];
                 for (int64_t t = s; t < e; ++t) if (!used[oM[t]]) kr_o[nkr++] = pos_of[oM[t]];
             }
-            out.child_ptr[i + 1] = (int32_t)out.child_list.size();
             out.knot_ptr[i + 1] = nkr;
         }
     }
     out.n_knot_rows = nkr;
+    if (!out.ext_perm) { out.perm.resize(out.P); out.src.resize(out.P); out.in_leaf.resize(out.P); }
     if (!out.ext_knot_rows) out.knot_rows.resize(nkr);
-    out.cw.assign(L, 0);
-    for (int m = 0; m < M; ++m) out.cw[m] = (r + 15) / 16 * 16;
-    out.preorder.clear();
-    out.preorder.reserve(nn);
-    {
-        std::vector<int64_t> st2;
-        st2.push_back(0);
-        while (!st2.empty()) {
-            const int64_t i = st2.back();
-            st2.pop_back();
-            out.preorder.push_back((int32_t)i);
-            if (!out.leaf[i]) {
-                const int m = out.level[i];
-                const int64_t c0 = out.level_ptr[m + 1] + 4 * (i - out.level_ptr[m]);
-                for (int c = 3; c >= 0; --c) st2.push_back(c0 + c);
-            }
-        }
-    }
     const double t_nodes = now();
     rng.final_state(mt_key, mt_pos);
-    if (trace) fprintf(stderr, "replay_quadtree N=%lld: partition %.1f ms, knots %.1f ms (candidates %.1f, shuffles %.1f of which target draws %.1f), layout join %.1f ms, node arrays %.1f ms, rng state %.1f ms\n",
-                       (long long)N, t_part - t_begin, t_knots - t_part, t_cand, t_shuf, t_gen, t_join - t_knots, t_nodes - t_join, now() - t_nodes);
+    if (trace) fprintf(stderr, "replay_quadtree N=%lld: partition done at %.1f ms, layout (+ hook) at %.1f ms; knots done at %.1f ms (candidates %.1f, shuffles %.1f of which target draws %.1f, waiting for the partition %.1f), join %.1f ms, knot rows %.1f ms, rng state %.1f ms\n",
+                       (long long)N, t_part - t_begin, t_layout - t_begin, t_knots - t_begin, t_cand, t_shuf, t_gen, t_wait, t_join - t_knots, t_nodes - t_join, now() - t_nodes);
     return 0;
 }
 
