@@ -109,6 +109,52 @@ hipError_t mraFree(void* p) {
     return hipSuccess;
 }
 
+// ---- stream cache: creating the two prioritised streams of a plan costs milliseconds (each is a hardware queue), destroying them
+// as much; a process that builds a new MRATree per objective call (README.md:96-104) gets the pair of the previous plan back
+namespace {
+struct StreamPair { hipStream_t hi, lo; double* host_res; double* host_res_dev; };      // + the pinned, device-mapped result record
+std::mutex g_streams_mu;
+std::multimap<int, StreamPair> g_streams;                           // device -> idle pair (both synchronised when they were returned)
+}  // namespace
+static void acquire_streams(mra_plan* pl) {
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        auto it = g_streams.find(pl->device);
+        if (it != g_streams.end()) {
+            pl->stream = it->second.hi; pl->stream2 = it->second.lo; pl->host_res = it->second.host_res; pl->host_res_dev = it->second.host_res_dev;
+            g_streams.erase(it);
+            return;
+        }
+    }
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&pl->stream, hipStreamDefault, hi));
+    HIP_TRY(hipStreamCreateWithPriority(&pl->stream2, hipStreamDefault, lo));
+}
+static void return_streams(mra_plan* pl) {
+    if (!pl->stream || !pl->stream2) {
+        if (pl->stream) hipStreamDestroy(pl->stream);
+        if (pl->stream2) hipStreamDestroy(pl->stream2);
+    } else {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        if (g_streams.count(pl->device) < 4) { g_streams.insert({pl->device, StreamPair{pl->stream, pl->stream2, pl->host_res, pl->host_res_dev}}); pl->host_res = nullptr; }
+        else { hipStreamDestroy(pl->stream); hipStreamDestroy(pl->stream2); }
+    }
+    if (pl->host_res) hipHostFree(pl->host_res);
+    pl->host_res = pl->host_res_dev = nullptr;
+    pl->stream = pl->stream2 = nullptr;
+}
+
+// a few host threads over a range of rows (or of leaves: min_per_thread is the smallest share worth a thread)
+template <class F>
+static void parallel_rows(int64_t n, F fn, int64_t min_per_thread = 65536) {
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::thread::hardware_concurrency()), n / min_per_thread));
+    if (T <= 1) { fn(0, n); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
+    for (auto& th : pool) th.join();
+}
+
 static void derive_kernel_params(KernelParams& kp) {
     kp.mode = 0; kp.a1 = 0.0; kp.a2 = 0.0; kp.amp = kp.scale * kp.sig;
     kp.inv_2l2 = 1.0 / (2.0 * (kp.l * kp.l));
@@ -129,6 +175,8 @@ static int fail(mra_plan* p, const MraError& e) {
     g_last_error = e.msg;
     return e.code;
 }
+
+static void fill_knot_arrays(mra_plan* pl);
 
 // ------------------------------------------------------------------------------------------------
 static void build_static(mra_plan* pl) {
@@ -178,20 +226,20 @@ static void build_static(mra_plan* pl) {
     HIP_TRY(mraMemset(pl->W.p, 0, pl->W.n * sizeof(double)));
     HIP_TRY(mraMemset(pl->var.p, 0, pl->var.n * sizeof(double)));
     HIP_TRY(mraMemset(pl->dnode.p, 0, pl->dnode.n * sizeof(double)));
-    pl->knots_dev.upload(pl->knot_rows);
+    pl->knots_dev.alloc((size_t)std::max<long>(pl->knot_ptr.back(), 1));       // contents: fill_knot_arrays
     tr.mark("checks, allocations, memsets");
 
-    // knot index arrays for the gather side of the prior GEMM (padded to cw with -1)
-    std::vector<int> kidx;
+    // knot index arrays for the gather side of the prior GEMM (padded to cw with -1): offsets here, contents in fill_knot_arrays
     pl->knot_idx_off.assign(pl->n_nodes, -1);
-    for (int i = 0; i < pl->n_nodes; ++i) {
-        if (pl->leaf[i]) continue;
-        const int m = pl->node_level[i];
-        pl->knot_idx_off[i] = (long)kidx.size();
-        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
-        for (int c = 0; c < pl->cw[m]; ++c) kidx.push_back(c < rk ? (int)pl->knot_rows[pl->knot_ptr[i] + c] : -1);
+    {
+        long tot = 0;
+        for (int i = 0; i < pl->n_nodes; ++i) {
+            if (pl->leaf[i]) continue;
+            pl->knot_idx_off[i] = tot;
+            tot += pl->cw[pl->node_level[i]];
+        }
+        pl->knot_idx.alloc((size_t)std::max<long>(tot, 1));
     }
-    pl->knot_idx.upload(kidx);
 
     // per level buffers + static descriptors
     pl->lev.clear();
@@ -441,10 +489,7 @@ static void build_static(mra_plan* pl) {
                 if (same_family) wgn.back() += cw / 16;
                 else { wg0.push_back((long)knot0.size()); wgn.push_back(cw / 16); }
                 for (int tt = 0; tt < cw / 16; ++tt) {
-                    for (int r = 0; r < 16; ++r) {
-                        const int c = tt * 16 + r;
-                        rows.push_back(c < rk ? (int)pl->knot_rows[pl->knot_ptr[i] + c] : -1);
-                    }
+                    for (int r = 0; r < 16; ++r) rows.push_back(-1);          // contents: fill_knot_arrays
                     for (int k = 0; k < 8; ++k) chain.push_back(ch[k]);
                     knot0.push_back(tt * 16);
                 }
@@ -573,6 +618,36 @@ static void build_static(mra_plan* pl) {
         }
         tr.mark("row tiles of the cascades");
     }
+    if (!pl->knots_pending) { fill_knot_arrays(pl); tr.mark("knot arrays"); }
+}
+
+// Everything in the plan that holds knot ROWS (as opposed to knot counts): the device copy of knot_rows, the padded per-node
+// index lists of the prior products, the knot row tiles of the fused levels.  The arrays are sized by build_static; a plan
+// built beside the knot draws (mra_plan_create_replay_2d) gets their contents here, once the draws are done.
+static void fill_knot_arrays(mra_plan* pl) {
+    if ((long)pl->knot_rows.size() != pl->knot_ptr.back()) throw MraError(MRA_ERR_INVALID, "knot_rows does not match knot_ptr");
+    if (!pl->knot_rows.empty()) pl->knots_dev.fill(pl->knot_rows);
+    std::vector<int> kidx(pl->knot_idx.n, -1);
+    for (int i = 0; i < pl->n_nodes; ++i) {
+        if (pl->leaf[i]) continue;
+        const int m = pl->node_level[i];
+        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+        for (int c = 0; c < pl->cw[m] && c < rk; ++c) kidx[pl->knot_idx_off[i] + c] = (int)pl->knot_rows[pl->knot_ptr[i] + c];
+    }
+    pl->knot_idx.fill(kidx);
+    if (pl->regular) {
+        const int cw = pl->cw[0];
+        for (int m = 0; m < pl->NL; ++m) {
+            const LevelData& lv = pl->lev[m];
+            std::vector<int> rows(lv.nodes.size() * (size_t)cw, -1);
+            for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
+                const int i = lv.nodes[sl];
+                const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+                for (int c = 0; c < cw && c < rk; ++c) rows[sl * cw + c] = (int)pl->knot_rows[pl->knot_ptr[i] + c];
+            }
+            pl->fl[m].kt_rows.fill(rows);
+        }
+    }
 }
 
 // leaf descriptors: depend on which rows are observed
@@ -583,20 +658,25 @@ static void build_leaf(mra_plan* pl, const double* y) {
     pl->leaf_nop.assign(nl, 0);
     pl->leaf_poff.assign(nl + 1, 0);
     pl->leaf_ioff.assign(nl + 1, 0);
-    std::vector<int> obs, opos(pl->P, -1), nobs(nl, 0);
+    // observed rows per leaf: counted and listed by a few threads over runs of leaves (one pass over y each)
+    std::vector<int> obs, opos(pl->P), nobs(nl, 0);
     std::vector<long> obs_off(nl + 1, 0);
+    const int64_t leaves_per_thread = std::max<int64_t>(1, (int64_t)(65536 * nl / std::max<long>(pl->P, 1)));
+    parallel_rows((int64_t)nl, [&](int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; ++t) {
+            const int i = pl->leaf_nodes[t];
+            int no = 0;
+            for (long p = pl->row0[i]; p < pl->row1[i]; ++p) no += std::isfinite(y[p]) ? 1 : 0;
+            nobs[t] = no;
+        }
+    }, leaves_per_thread);
     pl->leaf_max_rows = 0; pl->leaf_max_nop = 0; pl->leaf_max_na = 0; pl->leaf_max_ht = 0;
     for (size_t t = 0; t < nl; ++t) {
         const int i = pl->leaf_nodes[t];
         const int na = pl->na[pl->node_level[i]];
-        int no = 0;
-        obs_off[t] = (long)obs.size();
-        for (long p = pl->row0[i]; p < pl->row1[i]; ++p)
-            if (std::isfinite(y[p])) { obs.push_back((int)p); opos[p] = no; ++no; }
-        const int nop = (no + 15) / 16 * 16;
-        for (int k = no; k < nop; ++k) obs.push_back(-1);
+        const int no = nobs[t], nop = (no + 15) / 16 * 16;
+        obs_off[t + 1] = obs_off[t] + nop;
         pl->leaf_nop[t] = nop;
-        nobs[t] = no;
         const long nr = pl->row1[i] - pl->row0[i];
         pl->leaf_poff[t + 1] = pl->leaf_poff[t] + (long)(nop + na + nr) * nop;
         pl->leaf_ioff[t + 1] = pl->leaf_ioff[t] + (long)(nop / 16) * 256;
@@ -605,7 +685,26 @@ static void build_leaf(mra_plan* pl, const double* y) {
         pl->leaf_max_na = std::max(pl->leaf_max_na, na);
         pl->leaf_max_ht = std::max(pl->leaf_max_ht, (int)((nop + na + nr) / 16));
     }
-    obs_off[nl] = (long)obs.size();
+    obs.resize((size_t)obs_off[nl]);
+    {
+        // rows outside every leaf (orphan knot rows of a shard) are nobody's observation
+        long covered = 0;
+        for (size_t t = 0; t < nl; ++t) covered += pl->row1[pl->leaf_nodes[t]] - pl->row0[pl->leaf_nodes[t]];
+        if (covered != pl->P) std::fill(opos.begin(), opos.end(), -1);
+    }
+    parallel_rows((int64_t)nl, [&](int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; ++t) {
+            const int i = pl->leaf_nodes[t];
+            int* o = obs.data() + obs_off[t];
+            int no = 0;
+            for (long p = pl->row0[i]; p < pl->row1[i]; ++p) {
+                const bool f = std::isfinite(y[p]);
+                opos[p] = f ? no : -1;
+                if (f) o[no++] = (int)p;
+            }
+            for (int k = no; k < pl->leaf_nop[t]; ++k) o[k] = -1;
+        }
+    }, leaves_per_thread);
     pl->obs_idx.upload(obs); pl->obs_pos.upload(opos); pl->leaf_nobs.upload(nobs);
     tr.mark("observation lists");
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
@@ -1622,15 +1721,46 @@ static double* stage_buffer(size_t n) {               // caller holds g_stage_mu
     }
     return g_stage;
 }
-template <class F>
-static void parallel_rows(int64_t n, F fn) {
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4, std::thread::hardware_concurrency()), n / 65536));
-    if (T <= 1) { fn(0, n); return; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
-    for (auto& th : pool) th.join();
-}
 
+
+// knot coordinates of the fused levels (locs: P x d in padded leaf order): per level for the cascades, and packed per workgroup
+// for the knot chain
+static void set_knot_coords(mra_plan* pl, const double* locs) {
+    if (!pl->regular) return;
+    const int cw = pl->cw[0];
+    std::vector<std::vector<double>> kxh(pl->kc_levels);
+    for (int m = 0; m < pl->NL; ++m) {
+        const LevelData& lv = pl->lev[m];
+        std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d);
+        for (size_t e = 0; e < kx.size(); ++e)           // phantom knots: far away and far from each other
+            kx[e] = MRA_FAR_AWAY * (double)(2 + (e / pl->d) % cw);
+        for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
+            const int i = lv.nodes[sl];
+            const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+            for (long c = 0; c < rk; ++c)
+                for (int k = 0; k < pl->d; ++k)
+                    kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
+        }
+        HIP_TRY(mraMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (m < pl->kc_levels) kxh[m].swap(kx);
+    }
+    // k_knot_chain: every workgroup's knots of all its levels in one record (coordinates, then 1.0 / 0.0 = real / phantom)
+    if (pl->kc_levels >= 2 && pl->kc_knots.n) {
+        const int nlv = pl->kc_levels, d = pl->d;
+        const size_t rec = (size_t)cw * (d + 1), nb = pl->lev[nlv - 1].nodes.size();
+        std::vector<double> pk(nb * nlv * rec);
+        for (size_t b = 0; b < nb; ++b)
+            for (int m = 0; m < nlv; ++m) {
+                const int sl = pl->kc_chain_host[b * 8 + m];
+                const int i = pl->lev[m].nodes[sl];
+                const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
+                double* o = pk.data() + (b * nlv + m) * rec;
+                std::memcpy(o, kxh[m].data() + (size_t)sl * cw * d, (size_t)cw * d * sizeof(double));
+                for (int c = 0; c < cw; ++c) o[(size_t)cw * d + c] = c < rk ? 1.0 : 0.0;
+            }
+        HIP_TRY(mraMemcpy(pl->kc_knots.p, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 //  C ABI
@@ -1660,6 +1790,7 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
                 throw MraError(MRA_ERR_HIP, "no HIP device available: libmra_hip needs an AMD GPU (gfx950); there is no CPU fallback");
             if (device < 0 || device >= ndev) throw MraError(MRA_ERR_INVALID, "device ordinal out of range");
         }
+        PlanTrace tr("mra_plan_create");
         HIP_TRY(mraSetDevice(device));
         pl = new mra_plan();
         pl->device = device;
@@ -1675,29 +1806,29 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
         pl->knot_rows.assign(t->knot_rows, t->knot_rows + pl->knot_ptr.back());
         pl->cw.assign(t->cw, t->cw + t->n_levels);
         if (pl->level_ptr[0] != 0 || pl->level_ptr.back() != t->n_nodes) throw MraError(MRA_ERR_INVALID, "level_ptr inconsistent");
+        tr.mark("copies of the topology");
         if (!g_dry) {
             // The leaf update (one large GEMM) and [parent SYRK -> front Cholesky/Schur chain -> all-reduce of a sharded run]
             // only meet again in the predictive cascade: they are issued on two streams, so the collective and the
             // latency-bound chain never wait behind the update.  (On one GPU the update keeps every SIMD's register file
             // full and the pass time does not change; the point is the sharded run.)
-            int lo = 0, hi = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIP_TRY(hipStreamCreateWithPriority(&pl->stream, hipStreamDefault, hi));
-            HIP_TRY(hipStreamCreateWithPriority(&pl->stream2, hipStreamDefault, lo));
+            acquire_streams(pl);
             HIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
         }
         for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
-        { PlanTrace tr("mra_plan_create"); tr.mark("copies of the topology, streams, events"); }
+        tr.mark("streams, events");
         build_static(pl);
         *out = pl;
         return MRA_OK;
     } catch (const MraError& e) {
         int rc = fail(nullptr, e);
+        if (pl && !g_dry) return_streams(pl);
         delete pl;
         return rc;
     } catch (const std::exception& e) {
         g_last_error = e.what();
+        if (pl && !g_dry) return_streams(pl);
         delete pl;
         return MRA_ERR_INVALID;
     }
@@ -1715,17 +1846,25 @@ int mra_plan_destroy(mra_plan* pl) {
     if (pl->stream) hipStreamSynchronize(pl->stream);
     if (pl->stream2) hipStreamSynchronize(pl->stream2);
     for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
-    if (pl->stream) hipStreamDestroy(pl->stream);
-    if (pl->stream2) hipStreamDestroy(pl->stream2);
+    return_streams(pl);                              // (with the pinned result record)
     if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) hipEventDestroy(pl->ev_join);
-    if (pl->host_res) hipHostFree(pl->host_res);
     delete pl;
     return MRA_OK;
 }
 
 int mra_release_cached_memory(void) {
+    mra_topo::release_scratch();                      // the tree replay's work arrays (~100 MB at 1024^2, ~0.5 GB at config 5)
     if (g_dry) return MRA_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_streams_mu);
+        for (auto& e : g_streams) { hipStreamDestroy(e.second.hi); hipStreamDestroy(e.second.lo); if (e.second.host_res) hipHostFree(e.second.host_res); }
+        g_streams.clear();
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        if (g_stage) { hipHostFree(g_stage); g_stage = nullptr; g_stage_n = 0; }
+    }
     std::lock_guard<std::mutex> lock(g_pool.mu);
     g_pool.flush_locked();
     return MRA_OK;
@@ -1736,41 +1875,7 @@ int mra_plan_set_locs(mra_plan* pl, const double* locs) {
     try {
         HIP_TRY(mraSetDevice(pl->device));
         HIP_TRY(mraMemcpy(pl->X.p, locs, (size_t)pl->P * pl->d * sizeof(double), hipMemcpyHostToDevice));
-        if (pl->regular) {
-            const int cw = pl->cw[0];
-            std::vector<std::vector<double>> kxh(pl->kc_levels);
-            for (int m = 0; m < pl->NL; ++m) {
-                const LevelData& lv = pl->lev[m];
-                std::vector<double> kx(lv.nodes.size() * (size_t)cw * pl->d);
-                for (size_t e = 0; e < kx.size(); ++e)           // phantom knots: far away and far from each other
-                    kx[e] = MRA_FAR_AWAY * (double)(2 + (e / pl->d) % cw);
-                for (size_t sl = 0; sl < lv.nodes.size(); ++sl) {
-                    const int i = lv.nodes[sl];
-                    const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
-                    for (long c = 0; c < rk; ++c)
-                        for (int k = 0; k < pl->d; ++k)
-                            kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
-                }
-                HIP_TRY(mraMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
-                if (m < pl->kc_levels) kxh[m].swap(kx);
-            }
-            // k_knot_chain: every workgroup's knots of all its levels in one record (coordinates, then 1.0 / 0.0 = real / phantom)
-            if (pl->kc_levels >= 2 && pl->kc_knots.n) {
-                const int nlv = pl->kc_levels, d = pl->d;
-                const size_t rec = (size_t)cw * (d + 1), nb = pl->lev[nlv - 1].nodes.size();
-                std::vector<double> pk(nb * nlv * rec);
-                for (size_t b = 0; b < nb; ++b)
-                    for (int m = 0; m < nlv; ++m) {
-                        const int sl = pl->kc_chain_host[b * 8 + m];
-                        const int i = pl->lev[m].nodes[sl];
-                        const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
-                        double* o = pk.data() + (b * nlv + m) * rec;
-                        std::memcpy(o, kxh[m].data() + (size_t)sl * cw * d, (size_t)cw * d * sizeof(double));
-                        for (int c = 0; c < cw; ++c) o[(size_t)cw * d + c] = c < rk ? 1.0 : 0.0;
-                    }
-                HIP_TRY(mraMemcpy(pl->kc_knots.p, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
-            }
-        }
+        if (!pl->knots_pending) set_knot_coords(pl, locs);
         pl->have_locs = true;
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
@@ -1794,6 +1899,7 @@ int mra_plan_set_locs_rows(mra_plan* pl, const double* locs, const int64_t* src)
         tr.mark("upload X, knot coordinates");
         return rc;
     } catch (const MraError& e) { return fail(pl, e); }
+      catch (const std::exception& e) { return fail(pl, MraError(MRA_ERR_INVALID, e.what())); }       // bad_alloc, thread creation
 }
 
 int mra_plan_set_obs_rows(mra_plan* pl, const double* y, const int64_t* src, const int64_t* perm, double R) {
@@ -1809,6 +1915,7 @@ int mra_plan_set_obs_rows(mra_plan* pl, const double* y, const int64_t* src, con
         tr.mark("upload y, build_leaf");
         return rc;
     } catch (const MraError& e) { return fail(pl, e); }
+      catch (const std::exception& e) { return fail(pl, MraError(MRA_ERR_INVALID, e.what())); }       // bad_alloc, thread creation
 }
 
 int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_leaf, int64_t N, double* mean, double* var) {
@@ -1830,6 +1937,7 @@ int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_le
         });
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }
+      catch (const std::exception& e) { return fail(pl, MraError(MRA_ERR_INVALID, e.what())); }       // bad_alloc, thread creation
 }
 
 int mra_plan_set_obs(mra_plan* pl, const double* y, double R) {

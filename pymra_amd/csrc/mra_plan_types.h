@@ -128,6 +128,11 @@ struct DevVec {
             if (mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
         }
     }
+    // copy into the EXISTING allocation (descriptors already point into it)
+    void fill(const std::vector<T>& h) {
+        if (h.size() != n) throw MraError(MRA_ERR_STATE, "DevVec::fill: size changed");
+        if (n && mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
+    }
     void alloc(size_t count) {
         release();
         n = count;
@@ -181,6 +186,7 @@ struct mra_plan {
     long P = 0;
     int d = 0, n_levels = 0, n_nodes = 0;
     std::vector<long> level_ptr, row0, row1, knot_ptr, knot_rows;
+    bool knots_pending = false;         // mra_plan_create_replay_2d: built beside the knot draws; knot_rows (and the leaves' knot_ptr) arrive later (plan_set_knots)
     std::vector<uint8_t> leaf;
     std::vector<int> parent, child_ptr, child_list, cw, node_level;
     // layout

@@ -474,21 +474,26 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     const std::vector<int32_t>& oM = orders[M];
     double t_part = 0, t_layout = 0;
     std::atomic<int> layout_done{0};
-    auto layout = [&]() {
-        for (int64_t l = 0; l < nleaf; ++l) {
-            const int64_t c = starts[M][l + 1] - starts[M][l];
-            leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
-        }
-        out.P = leaf_off[nleaf];
+    // (rows: all team threads, a run of leaves each; node arrays and the hook: thread 0)
+    auto layout_rows = [&](int tid) {
         int64_t* const perm_o = out.ext_perm ? out.ext_perm : out.perm.data();
         int64_t* const src_o = out.ext_perm ? out.ext_src : out.src.data();
         uint8_t* const inl_o = out.ext_perm ? out.ext_in_leaf : out.in_leaf.data();
-        for (int64_t l = 0; l < nleaf; ++l) {
+        for (int64_t l = nleaf * tid / n_team; l < nleaf * (tid + 1) / n_team; ++l) {
             const int64_t s = starts[M][l], e = starts[M][l + 1];
             int64_t p = leaf_off[l];
             for (int64_t t = s; t < e; ++t, ++p) { perm_o[p] = oM[t]; src_o[p] = oM[t]; inl_o[p] = 1; pos_of[oM[t]] = p; }
             for (; p < leaf_off[l + 1]; ++p) { perm_o[p] = -1; src_o[p] = oM[s]; inl_o[p] = 0; }      // phantom rows copy the leaf's first location
         }
+    };
+    auto layout_offsets = [&]() {
+        for (int64_t l = 0; l < nleaf; ++l) {
+            const int64_t c = starts[M][l + 1] - starts[M][l];
+            leaf_off[l + 1] = leaf_off[l] + (c + 15) / 16 * 16;
+        }
+        out.P = leaf_off[nleaf];
+    };
+    auto layout = [&]() {
         // node arrays (knot_ptr: the non-leaf nodes' r knots each; the leaves' entries follow with the knots)
         size_t nchild = 0;
         for (int m = 0; m < L; ++m) {
@@ -529,9 +534,13 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
     for (int t = 0; t < n_team; ++t)
         pool.emplace_back([&, t]() {
             team(t);
+            if (bad.load()) return;                        // (set before a barrier every thread of the team passes: all of them see it)
+            if (t == 0) { t_part = now(); layout_offsets(); }
+            bar.wait();
+            layout_rows(t);
+            bar.wait();
             if (t == 0) {
-                t_part = now();
-                if (!bad.load()) layout();
+                layout();
                 t_layout = now();
                 layout_done.store(1, std::memory_order_release);
             }
