@@ -223,6 +223,17 @@ int mra_tree_replay_2d(const double *locs, int64_t N, int32_t r, int32_t M, uint
 int mra_tree_replay_2d_into(const double *locs, int64_t N, int32_t r, int32_t M, uint32_t *mt_key, int32_t *mt_pos,
                             int64_t cap_rows, int64_t *perm, int64_t *src, uint8_t *in_leaf, int64_t *knot_rows,
                             mra_tree **out);
+/* MRATree.__init__ for large 2-D trees in ONE call (pyMRA/MRATree.py:61-69 -> Node.__init__, MRANode.py:23-115): the replay
+ * of mra_tree_replay_2d_into AND mra_plan_create + mra_plan_set_locs_rows + mra_plan_set_obs_rows, overlapped - the plan is sized,
+ * allocated and fed its locations (locs: the caller's N x 2 rows) and observations (y: N values, NaN = missing; R: nugget) on a
+ * helper thread while the calling thread draws the knots.  On success *tree_out is the tree (mra_tree_sizes / mra_tree_export /
+ * mra_tree_free as usual; perm, src, in_leaf, knot_rows are written to the caller's buffers) and *plan_out a plan that only
+ * needs mra_plan_set_kernel before mra_run.  Returns 1 - nothing created, RNG state untouched - when the tree does not follow
+ * the large-2-D rules (use mra_tree_replay / the Python replay and mra_plan_create then), < 0 on errors. */
+int mra_plan_create_replay_2d(const double *locs, int64_t N, int32_t r, int32_t M, uint32_t *mt_key, int32_t *mt_pos,
+                              const double *y, double R, int device, int64_t cap_rows,
+                              int64_t *perm, int64_t *src, uint8_t *in_leaf, int64_t *knot_rows,
+                              mra_tree **tree_out, mra_plan **plan_out);
 /* out5 = {P, n_nodes, n_levels, len(child_list), len(knot_rows)} */
 int mra_tree_sizes(mra_tree *t, int64_t *out5);
 /* copies the arrays of `mra_topology` (+ perm, src, in_leaf, node_level, pre-order) into caller buffers */

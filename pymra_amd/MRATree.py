@@ -31,7 +31,7 @@ import logging
 import numpy as np
 
 from . import MRATools as mt
-from .plan import HipPlan
+from .plan import HipPlan, create_with_replay
 from .topology import build_topology, resolve_tree_shape
 
 logger = logging.getLogger("pyMRA.MRATree")
@@ -116,10 +116,16 @@ class MRATree(object):
         self.kernel = spec          # None: opaque callable / dense matrix -> values come from the host
 
         logger.debug('r: %d, \tJ: %d,\tM: %d' % (self.r, self.J, self.M))
-        self.topology = build_topology(np.asarray(locs, dtype=np.float64), r, self.M, self.J)
-        self.plan = HipPlan(self.topology, device=device)
-        self.plan.set_locs(locs)
-        self.plan.set_obs(obs_arr, R)
+        # large 2-D trees: tree replay, plan construction and the uploads in one library call (the plan is built beside the
+        # sequential knot draws); everything else - 1-D, small nodes, KMeans rules - the general path
+        both = create_with_replay(locs, r, self.M, self.J, obs_arr, R, device) if self.d == 2 else None
+        if both is not None:
+            self.plan, self.topology = both
+        else:
+            self.topology = build_topology(np.asarray(locs, dtype=np.float64), r, self.M, self.J)
+            self.plan = HipPlan(self.topology, device=device)
+            self.plan.set_locs(locs)
+            self.plan.set_obs(obs_arr, R)
         if spec is not None:
             self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale, spec.circular)
         else:

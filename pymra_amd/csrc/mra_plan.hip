@@ -1725,7 +1725,10 @@ static double* stage_buffer(size_t n) {               // caller holds g_stage_mu
 
 // knot coordinates of the fused levels (locs: P x d in padded leaf order): per level for the cascades, and packed per workgroup
 // for the knot chain
-static void set_knot_coords(mra_plan* pl, const double* locs) {
+static void set_knot_coords_src(mra_plan* pl, const double* locs, const int64_t* src);
+static void set_knot_coords(mra_plan* pl, const double* locs) { set_knot_coords_src(pl, locs, nullptr); }
+// (src: locs is the CALLER's N x d array and padded row p holds caller row src[p]; nullptr: locs is already in padded order)
+static void set_knot_coords_src(mra_plan* pl, const double* locs, const int64_t* src) {
     if (!pl->regular) return;
     const int cw = pl->cw[0];
     std::vector<std::vector<double>> kxh(pl->kc_levels);
@@ -1739,7 +1742,7 @@ static void set_knot_coords(mra_plan* pl, const double* locs) {
             const long rk = pl->knot_ptr[i + 1] - pl->knot_ptr[i];
             for (long c = 0; c < rk; ++c)
                 for (int k = 0; k < pl->d; ++k)
-                    kx[(sl * cw + c) * pl->d + k] = locs[pl->knot_rows[pl->knot_ptr[i] + c] * pl->d + k];
+                    kx[(sl * cw + c) * pl->d + k] = locs[(src ? src[pl->knot_rows[pl->knot_ptr[i] + c]] : pl->knot_rows[pl->knot_ptr[i] + c]) * pl->d + k];
         }
         HIP_TRY(mraMemcpy(pl->fl[m].kx.p, kx.data(), kx.size() * sizeof(double), hipMemcpyHostToDevice));
         if (m < pl->kc_levels) kxh[m].swap(kx);
@@ -2309,6 +2312,124 @@ int mra_tree_replay_2d_into(const double* locs, int64_t N, int32_t r, int32_t M,
     catch (const std::exception& e) { g_last_error = e.what(); delete t; return MRA_ERR_INVALID; }
     if (rc != 0) { delete t; return 1; }
     *out = t;
+    return MRA_OK;
+}
+
+// ---- MRATree.__init__ for large 2-D trees in one call ---------------------------------------------------------------------------
+// The tree replay and the plan construction of an end-to-end MRATree(...) call, overlapped: as soon as the replay has the
+// partition and the row layout (everything but the knots), a helper thread sizes and allocates the plan, gathers and uploads the
+// locations and the observations and builds the leaf descriptors - while the caller's thread is still drawing knots, the one
+// sequential part (it has to consume NumPy's MT19937 stream in the reference's order).  The knot rows, the leaves' knot
+// counts and the knot coordinates go in when both are done.
+namespace {
+struct ReplayPlanCtx {
+    const double* locs; const double* y; double R; int device;
+    mra_plan* pl = nullptr;
+    int rc = MRA_OK;
+    std::string err;
+};
+void replay_plan_hook(void* user, const mra_topo::Result& t) {
+    ReplayPlanCtx& c = *(ReplayPlanCtx*)user;
+    mra_plan* pl = nullptr;
+    try {
+        PlanTrace tr("plan beside the knot draws");
+        int ndev = 0;
+        if (!g_dry) {
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+                throw MraError(MRA_ERR_HIP, "no HIP device available: libmra_hip needs an AMD GPU (gfx950); there is no CPU fallback");
+            if (c.device < 0 || c.device >= ndev) throw MraError(MRA_ERR_INVALID, "device ordinal out of range");
+        }
+        HIP_TRY(mraSetDevice(c.device));
+        pl = new mra_plan();
+        pl->device = c.device;
+        pl->knots_pending = true;
+        pl->P = t.P; pl->d = 2; pl->n_levels = t.n_levels; pl->n_nodes = t.n_nodes;
+        pl->level_ptr.assign(t.level_ptr.begin(), t.level_ptr.end());
+        pl->row0.assign(t.row0.begin(), t.row0.end());
+        pl->row1.assign(t.row1.begin(), t.row1.end());
+        pl->leaf.assign(t.leaf.begin(), t.leaf.end());
+        pl->parent.assign(t.parent.begin(), t.parent.end());
+        pl->child_ptr.assign(t.child_ptr.begin(), t.child_ptr.end());
+        pl->child_list.assign(t.child_list.begin(), t.child_list.end());
+        pl->knot_ptr.assign(t.knot_ptr.begin(), t.knot_ptr.end());      // non-leaf nodes final; the leaves' entries are provisional
+        pl->cw.assign(t.cw.begin(), t.cw.end());
+        if (!g_dry) {
+            acquire_streams(pl);
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+        }
+        for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
+        tr.mark("copies of the topology, streams, events");
+        build_static(pl);
+        tr.mark("build_static");
+        const int64_t* src = t.ext_perm ? t.ext_src : t.src.data();
+        const int64_t* perm = t.ext_perm ? t.ext_perm : t.perm.data();
+        {
+            std::lock_guard<std::mutex> lock(g_stage_mutex);
+            double* xp = stage_buffer((size_t)pl->P * 3);
+            double* yp = xp + (size_t)pl->P * 2;
+            const double nan = std::nan("");
+            const double* locs = c.locs; const double* y = c.y;
+            parallel_rows(pl->P, [&](int64_t a, int64_t b) {
+                for (int64_t p = a; p < b; ++p) {
+                    const int64_t q = src[p];
+                    xp[2 * p] = locs[2 * q]; xp[2 * p + 1] = locs[2 * q + 1];
+                    yp[p] = perm[p] < 0 ? nan : y[q];
+                }
+            });
+            tr.mark("gather locations and observations");
+            int rc = mra_plan_set_locs(pl, xp);
+            if (rc == MRA_OK) rc = mra_plan_set_obs(pl, yp, c.R);
+            if (rc != MRA_OK) throw MraError(rc, pl->err);
+            tr.mark("uploads, leaf descriptors");
+        }
+        c.pl = pl;
+    } catch (const MraError& e) {
+        c.rc = e.code; c.err = e.msg;
+        if (pl) { if (!g_dry) return_streams(pl); delete pl; }
+    } catch (const std::exception& e) {
+        c.rc = MRA_ERR_INVALID; c.err = e.what();
+        if (pl) { if (!g_dry) return_streams(pl); delete pl; }
+    }
+}
+}  // namespace
+
+int mra_plan_create_replay_2d(const double* locs, int64_t N, int32_t r, int32_t M, uint32_t* mt_key, int32_t* mt_pos,
+                              const double* y, double R, int device, int64_t cap_rows,
+                              int64_t* perm, int64_t* src, uint8_t* in_leaf, int64_t* knot_rows, mra_tree** tree_out, mra_plan** plan_out) {
+    if (!locs || !mt_key || !mt_pos || !y || !tree_out || !plan_out || !perm || !src || !in_leaf || !knot_rows) return MRA_ERR_INVALID;
+    *tree_out = nullptr; *plan_out = nullptr;
+    if (M < 0 || M > 15 || cap_rows < N + 15 * ((int64_t)1 << (2 * M))) { g_last_error = "mra_plan_create_replay_2d: cap_rows must be at least N + 15 * 4^M"; return MRA_ERR_INVALID; }
+    if (!(R > 0.0)) { g_last_error = "R must be a positive scalar"; return MRA_ERR_INVALID; }
+    mra_tree* t = new mra_tree();
+    t->r.ext_perm = perm; t->r.ext_src = src; t->r.ext_in_leaf = in_leaf; t->r.ext_knot_rows = knot_rows;
+    ReplayPlanCtx ctx{locs, y, R, device};
+    int rc;
+    try { rc = mra_topo::replay_quadtree(locs, N, r, M, mt_key, mt_pos, t->r, replay_plan_hook, &ctx); }
+    catch (const std::exception& e) { g_last_error = e.what(); rc = MRA_ERR_INVALID; }
+    mra_plan* pl = ctx.pl;
+    if (rc == 0 && ctx.rc != MRA_OK) { g_last_error = ctx.err; rc = ctx.rc; }
+    if (rc != 0) {                                           // not a large-2-D tree (1), or an error: nothing is handed out
+        if (pl) mra_plan_destroy(pl);
+        delete t;
+        return rc;
+    }
+    try {
+        PlanTrace tr("knots into the plan");
+        HIP_TRY(mraSetDevice(pl->device));
+        pl->knot_ptr.assign(t->r.knot_ptr.begin(), t->r.knot_ptr.end());
+        pl->knot_rows.assign(knot_rows, knot_rows + t->r.n_knot_rows);
+        pl->knots_pending = false;
+        fill_knot_arrays(pl);
+        set_knot_coords_src(pl, locs, src);                  // knot coordinates straight from the caller's rows
+    } catch (const MraError& e) {
+        const int code = fail(nullptr, e);
+        mra_plan_destroy(pl);
+        delete t;
+        return code;
+    }
+    *tree_out = t;
+    *plan_out = pl;
     return MRA_OK;
 }
 

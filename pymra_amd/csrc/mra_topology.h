@@ -510,6 +510,7 @@ inline int replay_quadtree(const double* xy, int64_t N, int32_t r, int32_t M, ui
                 out.knot_ptr[i + 1] = m < M ? (i + 1) * (int64_t)r : out.knot_ptr[i];      // (leaves: provisional, empty)
             }
         }
+        out.knot_ptr[nn_all] = N;                          // every caller row is the knot of exactly one node: the total is known
         for (int m = 0; m < M; ++m) out.cw[m] = (r + 15) / 16 * 16;
         {
             size_t np = 0;

@@ -43,7 +43,7 @@ EXPORTS = [
     "mra_get_kernel_stats", "mra_get_kernel_work", "mra_device_synchronize", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
     "mra_run_resume", "mra_last_error", "mra_version",
-    "mra_tree_replay_2d", "mra_tree_replay_2d_into", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
+    "mra_tree_replay_2d", "mra_tree_replay_2d_into", "mra_plan_create_replay_2d", "mra_tree_sizes", "mra_tree_export", "mra_tree_free",
 ]
 
 
@@ -110,6 +110,8 @@ def load_library():
         "mra_reduce_import": (C.c_int, [vp, vp]),
         "mra_tree_replay_2d": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), C.POINTER(vp)]),
         "mra_tree_replay_2d_into": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), i64, vp, vp, vp, vp, C.POINTER(vp)]),
+        "mra_plan_create_replay_2d": (C.c_int, [vp, i64, i32, i32, vp, C.POINTER(i32), vp, dbl, C.c_int, i64, vp, vp, vp, vp,
+                                                C.POINTER(vp), C.POINTER(vp)]),
         "mra_tree_sizes": (C.c_int, [vp, vp]),
         "mra_tree_export": (C.c_int, [vp] + [vp] * 15),
         "mra_tree_free": (C.c_int, [vp]),
@@ -131,10 +133,15 @@ def _ptr(a):
 class HipPlan:
     """One MRA tree on one GPU.  Thin, stateful wrapper of the C ABI."""
 
-    def __init__(self, topo, device: int = 0):
+    def __init__(self, topo, device: int = 0, _handle=None):
         self.lib = load_library()
         self.topo = topo
         self._h = C.c_void_p()
+        if _handle is not None:                  # a plan the library has already built (create_with_replay)
+            self._h = _handle
+            self.P = int(topo.P)
+            self.d = int(topo.d)
+            return
         # keep the arrays alive (and of the exact dtypes the header declares) during the call
         arrs = dict(
             level_ptr=np.ascontiguousarray(topo.level_ptr, dtype=np.int64),
@@ -343,6 +350,44 @@ class HipPlan:
 
     def comm_init(self, uid: bytes, n_ranks: int, rank: int):
         self._check(self.lib.mra_comm_init(self._h, uid, int(n_ranks), int(rank)))
+
+
+def create_with_replay(locs, r, M, J, obs, R, device: int = 0):
+    """MRATree.__init__ for large 2-D trees in one library call (mra_plan_create_replay_2d): the tree replay and, beside its
+    sequential knot draws, the plan with locations and observations already uploaded.  Consumes NumPy's global RNG exactly like
+    pymra_amd.topology.build_topology.  Returns (HipPlan, Topology), or None when the tree does not follow the large-2-D rules
+    (RNG state untouched: the caller takes the general path)."""
+    from .topology import topology_from_tree
+    coords = np.ascontiguousarray(np.asarray(locs, dtype=np.float64))
+    if coords.ndim != 2 or coords.shape[1] != 2 or J != 4 or M < 1:
+        return None
+    y = np.ascontiguousarray(np.asarray(obs, dtype=np.float64).reshape(-1))
+    N = len(coords)
+    if len(y) != N:
+        raise ValueError("obs must have N entries")
+    state = np.random.get_state()
+    if state[0] != "MT19937":
+        return None
+    lib = load_library()
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(state[2]))
+    cap = N + 15 * 4 ** int(M)
+    perm, src = np.empty(cap, np.int64), np.empty(cap, np.int64)
+    in_leaf, knot_rows = np.empty(cap, np.bool_), np.empty(N, np.int64)
+    tree, ph = C.c_void_p(), C.c_void_p()
+    rc = lib.mra_plan_create_replay_2d(_ptr(coords), N, int(r), int(M), _ptr(key), C.byref(pos), _ptr(y), float(R), int(device), cap,
+                                       _ptr(perm), _ptr(src), _ptr(in_leaf), _ptr(knot_rows), C.byref(tree), C.byref(ph))
+    if rc == 1:
+        return None
+    if rc != 0:
+        msg = lib.mra_last_error(None)
+        raise MraError(rc, msg.decode() if msg else "")
+    try:
+        topo = topology_from_tree(lib, tree, N, int(r), int(M), int(J), perm, src, in_leaf, knot_rows)
+    finally:
+        lib.mra_tree_free(tree)
+    np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    return HipPlan(topo, device, _handle=ph), topo
 
 
 def comm_unique_id() -> bytes:

@@ -312,22 +312,31 @@ def _replay_native(coords: np.ndarray, r: int, M: int, J: int) -> Optional[Topol
     if rc != 0:
         return None
     try:
-        sz = np.zeros(5, dtype=np.int64)
-        lib.mra_tree_sizes(handle, vp(sz))
-        P, n_nodes, n_levels, n_child, n_knots = (int(v) for v in sz)
-        a = dict(perm=None, src=None, in_leaf=None,
-                 level_ptr=np.empty(n_levels + 1, np.int64), node_level=np.empty(n_nodes, np.int32),
-                 row0=np.empty(n_nodes, np.int64), row1=np.empty(n_nodes, np.int64), leaf=np.empty(n_nodes, np.uint8),
-                 parent=np.empty(n_nodes, np.int32), child_ptr=np.empty(n_nodes + 1, np.int32),
-                 child_list=np.empty(n_child, np.int32), knot_ptr=np.empty(n_nodes + 1, np.int64),
-                 knot_rows=None, cw=np.empty(n_levels, np.int32), pre=np.empty(n_nodes, np.int32))
-        lib.mra_tree_export(handle, *[None if v is None else vp(v) for v in a.values()])
-        a.update(perm=perm[:P], src=src[:P], in_leaf=in_leaf[:P], knot_rows=knot_rows[:n_knots])
+        topo = topology_from_tree(lib, handle, N, r, M, J, perm, src, in_leaf, knot_rows)
     finally:
         lib.mra_tree_free(handle)
     np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    return topo
+
+
+def topology_from_tree(lib, handle, N, r, M, J, perm, src, in_leaf, knot_rows) -> Topology:
+    """The Topology of a native replay: the node arrays exported from the library's tree handle, the four long arrays
+    (already written into the caller's buffers by the replay) cut to their sizes."""
+    import ctypes as C
+    vp = lambda v: v.ctypes.data_as(C.c_void_p)
+    sz = np.zeros(5, dtype=np.int64)
+    lib.mra_tree_sizes(handle, vp(sz))
+    P, n_nodes, n_levels, n_child, n_knots = (int(v) for v in sz)
+    a = dict(perm=None, src=None, in_leaf=None,
+             level_ptr=np.empty(n_levels + 1, np.int64), node_level=np.empty(n_nodes, np.int32),
+             row0=np.empty(n_nodes, np.int64), row1=np.empty(n_nodes, np.int64), leaf=np.empty(n_nodes, np.uint8),
+             parent=np.empty(n_nodes, np.int32), child_ptr=np.empty(n_nodes + 1, np.int32),
+             child_list=np.empty(n_child, np.int32), knot_ptr=np.empty(n_nodes + 1, np.int64),
+             knot_rows=None, cw=np.empty(n_levels, np.int32), pre=np.empty(n_nodes, np.int32))
+    lib.mra_tree_export(handle, *[None if v is None else vp(v) for v in a.values()])
+    a.update(perm=perm[:P], src=src[:P], in_leaf=in_leaf[:P], knot_rows=knot_rows[:n_knots])
     idents = _LazyIdents(a["parent"], a["node_level"], a["level_ptr"])
-    return Topology(N=len(xy), d=2, M=M, J=J, r=r, P=P, perm=a["perm"], src=a["src"], in_leaf=a["in_leaf"],
+    return Topology(N=N, d=2, M=M, J=J, r=r, P=P, perm=a["perm"], src=a["src"], in_leaf=a["in_leaf"],
                     n_nodes=n_nodes, n_levels=n_levels, level_ptr=a["level_ptr"], node_level=a["node_level"],
                     node_row0=a["row0"], node_row1=a["row1"], node_leaf=a["leaf"].astype(bool), node_parent=a["parent"],
                     child_ptr=a["child_ptr"], child_list=a["child_list"], knot_ptr=a["knot_ptr"], knot_rows=a["knot_rows"],

@@ -63,6 +63,30 @@ for n, r, M in ((48, 16, 2), (128, 32, 3), (256, 64, 3), (200, 16, 4)):
     for frac in (0.0, 0.4, 1.0):
         y = np.where(np.random.uniform(size=(n * n, 1)) < frac, np.random.normal(size=(n * n, 1)), np.nan)
         build(topo, locs, y, 1e-2)
+    # the one-call constructor path (replay + plan beside the knot draws): same tree, same RNG state, a plan that is complete
+    np.random.seed(3)
+    st0 = np.random.get_state()
+    both = P.create_with_replay(locs, r, M, 4, y, 1e-2)
+    assert both is not None
+    pl2, topo2 = both
+    st1 = np.random.get_state()
+    np.random.set_state(st0)
+    topo3 = build_topology(locs, r, M, 4)
+    st2 = np.random.get_state()
+    assert np.array_equal(st1[1], st2[1]) and st1[2] == st2[2]
+    for f in ("perm", "src", "in_leaf", "level_ptr", "node_row0", "node_row1", "node_leaf", "node_parent", "child_ptr", "child_list",
+              "knot_ptr", "knot_rows", "cw", "order_preorder"):
+        assert np.array_equal(getattr(topo2, f), getattr(topo3, f)), f
+    pl2.set_kernel(mt.KIND_MATERN32, 0.3, 1.0, 1.0)
+    assert pl2.info()["P"] == topo3.P
+    pl2.close(); n_plans += 1
+# a tree the one-call path must decline (nodes with <= 100 rows), leaving the RNG state alone
+np.random.seed(4)
+locs = mt.genLocations2d(Nx=40, Ny=40)
+st0 = np.random.get_state()
+assert P.create_with_replay(locs, 16, 3, 4, np.zeros(1600), 1e-2) is None
+st1 = np.random.get_state()
+assert np.array_equal(st0[1], st1[1]) and st0[2] == st1[2]
 print("ASAN_HOST_OK", n_plans)
 '''
 

@@ -627,6 +627,37 @@ def test_no_buffer_relies_on_zero_initialised_memory(hip):
         hip.release_cached_memory()
 
 
+@pytest.mark.parametrize("n,r,M", [(64, 16, 2), (200, 16, 3), (256, 32, 3)])
+def test_one_call_constructor_equals_the_stepwise_path(hip, n, r, M):
+    """MRATree(...) builds large 2-D trees through mra_plan_create_replay_2d (tree replay with the plan constructed beside the
+    knot draws).  Same seed, same inputs: the tree, NumPy's RNG state afterwards, the likelihood and the predictions must be
+    bit-identical to build_topology -> HipPlan -> set_locs -> set_obs."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd import MRATree
+    from pymra_amd.topology import build_topology
+    np.random.seed(31)
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y_obs = np.where(np.random.uniform(size=(n * n, 1)) < 0.4, np.random.normal(size=(n * n, 1)), np.nan)
+    st0 = np.random.get_state()
+    cov = lambda a, b: mt.Matern32(a, b, l=0.25, sig=1.1)
+    tree = MRATree(locs, r, cov, y_obs, 2e-2, M=M, J=4)
+    st1 = np.random.get_state()
+    lik = float(tree.getLikelihood()[0, 0])
+    mean, sd = tree.predict()
+    np.random.set_state(st0)
+    topo = build_topology(locs, r, M, 4)
+    st2 = np.random.get_state()
+    assert np.array_equal(st1[1], st2[1]) and st1[2] == st2[2]
+    for f in ("perm", "src", "in_leaf", "node_row0", "node_row1", "knot_ptr", "knot_rows", "child_list", "order_preorder"):
+        assert np.array_equal(getattr(tree.topology, f), getattr(topo, f)), f
+    pl = hip.HipPlan(topo, 0); pl.set_locs(locs); pl.set_obs(y_obs, 2e-2); pl.set_kernel(mt.KIND_MATERN32, 0.25, 1.1, 1.0)
+    pl.run(True, True)
+    m2, v2 = pl.predict()
+    assert sum(pl.likelihood()) == lik
+    assert np.array_equal(np.asarray(mean).ravel(), m2) and np.array_equal(sd, np.sqrt(v2))
+    pl.close(); tree.plan.close()
+
+
 def test_root_view_attributes(hip):
     import pymra_amd
     import pymra_amd.MRATools as mt
