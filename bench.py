@@ -204,6 +204,34 @@ def mle_throughput(pl, c, kind, y_obs, red=-1, host_allreduce=None, rank=0, dist
     return out
 
 
+def traffic_from_profiles(kernel_family, profiles_dir=None):
+    """(hbm bytes per launch, raw counters, source file, note) of a kernel family from the newest PMC summary under profiles/.
+    The counters cannot be collected inside this process (they need rocprofv3 around it), so the summary of the round's
+    collection is quoted - but only if it was collected from the kernel sources that are in the tree now (tools/csrc_hash.py):
+    after any change under pymra_amd/csrc the bytes are unknown until tools/collect_profiles.sh has run again."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_sha256
+    cands = sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_pmc_traffic_by_kernel_family.json")))
+    if not cands:
+        return None, None, None, "no PMC summary under profiles/"
+    src = os.path.basename(cands[-1])
+    try:
+        summ = json.load(open(cands[-1]))
+    except Exception as e:                                    # pragma: no cover
+        return None, None, src, "unreadable summary: %r" % (e,)
+    stamp = (summ.get("_collected_from") or {}).get("csrc_sha256")
+    if stamp is None:
+        return None, None, src, "%s carries no source stamp (collected before round 4)" % src
+    if stamp != csrc_sha256():
+        return None, None, src, "%s was collected from other kernel sources (stamp %s...): run tools/collect_profiles.sh again" % (src, stamp[:12])
+    fam = summ.get(kernel_family)
+    if not fam or "hbm_bytes_per_launch" not in fam:
+        return None, None, src, "%s has no counters for this kernel family" % src
+    return (fam["hbm_bytes_per_launch"], {"FETCH_SIZE_KB": fam.get("FETCH_SIZE_KB_per_launch_mean"), "WRITE_SIZE_KB": fam.get("WRITE_SIZE_KB_per_launch_mean")},
+            src, None)
+
+
 def relaunch_with_ranks(n):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, as a CHILD process -
     `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` on a free local port - before anything
@@ -381,20 +409,11 @@ def main():
         dom_fl = dom["flops"] / max(dom["launches"], 1)
         ach = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         # HBM traffic of the dominant kernel from the committed PMC summary of this same command
-        # (tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)
-        traffic, traffic_raw, traffic_src = None, None, None
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_by_kernel_family.json")))
-        if cands:
-            try:
-                fam = json.load(open(cands[-1])).get(dom["name"])
-                if fam:
-                    traffic = fam.get("hbm_bytes_per_launch")
-                    traffic_raw = {"FETCH_SIZE_KB": fam.get("FETCH_SIZE_KB_per_launch_mean"),
-                                   "WRITE_SIZE_KB": fam.get("WRITE_SIZE_KB_per_launch_mean")}
-                    traffic_src = os.path.basename(cands[-1])
-            except Exception:
-                pass
+        # (tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction) - quoted only while the
+        # summary's stamp matches the kernel sources this library was built from, null (with a note) otherwise
+        traffic, traffic_raw, traffic_src, traffic_note = traffic_from_profiles(dom["name"])
+        if traffic_note:
+            print("bench.py: roofline.traffic is null: %s" % traffic_note, file=sys.stderr)
         # "achieved"/"frac" are strictly algorithmic: flops counted with the true ranks, the true observation counts and a
         # one-column y (mra_plan.hip: struct Work); the rate of the MFMAs the 16-padded tiles actually execute is reported
         # separately as mfma_executed_tflops.  Every family also shows its algorithmic HBM bytes against the 8 TB/s roof,
@@ -412,7 +431,7 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "peak_measured": FP64_MFMA_MEASURED_TFLOPS,
                 "frac_of_measured": ach / FP64_MFMA_MEASURED_TFLOPS,
                 "mfma_executed_tflops": dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
-                "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_source": traffic_src, "traffic_note": traffic_note,
                 "hbm_bytes_algorithmic": dom["bytes"] / max(dom["launches"], 1),
                 "hbm_frac": (dom["bytes"] / max(dom["launches"], 1)) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else 0.0,
                 "avg_launch_ms": dom_ms, "flop_per_launch": dom_fl,

@@ -90,11 +90,19 @@ struct KernelParams {
 };
 #define MRA_FAR_AWAY 1.0e150   /* coordinate of a phantom knot: every kernel gives exactly 0 there */
 
-// exp(-t), t >= 0: t = k ln2 + r, |r| <= ln2/2, degree-13 Taylor (remainder < 4e-18), v_ldexp_f64.
-// The ocml exp()/sqrt() are an order of magnitude more instructions (denormal/NaN/overflow care that
-// cannot occur here) and made the covariance evaluation the bottleneck of every kernel using it.
-__device__ __forceinline__ double exp_neg(double t) {
-    t = fmin(t, 1100.0);
+// exp(-t), t >= 0.  The ocml exp()/sqrt() are an order of magnitude more instructions (denormal/NaN/overflow care that cannot
+// occur here) and made the covariance evaluation the bottleneck of every kernel using it; and FP64 VALU work shares the pipe
+// with the FP64 MFMAs, so every instruction of an evaluation is taken from the matrix rate.
+//   MRA_EXP_VARIANT 0: t = k ln2 + r, |r| <= ln2/2, degree-13 Taylor (remainder < 4e-18), v_ldexp_f64: 21 FP64 instructions
+//   MRA_EXP_VARIANT 2: t = (64 k + j) ln2/64 + r, |r| <= ln2/128, degree-5 Taylor (remainder 3.5e-17 relative), times 2^(-j/64)
+//                      from a 64-entry table that lives ONE ENTRY PER LANE in a register pair (computed from the lane number,
+//                      which the compiler hoists to the top of the kernel) and is read with two ds_bpermute_b32 - the LDS
+//                      crossbar, not the FP64 pipe: 12 FP64 instructions
+//   MRA_EXP_VARIANT 1: quarter steps, t = (4 k + j) ln2/4 + r, |r| <= ln2/8, degree 9, 2^(-j/4) by selects: 16 FP64 instructions
+#ifndef MRA_EXP_VARIANT
+#define MRA_EXP_VARIANT 2
+#endif
+__device__ __forceinline__ double exp_neg_poly13(double t) {
     const double kf = __builtin_rint(t * 1.4426950408889634074);
     double r = __builtin_fma(kf, 6.93147180369123816490e-01, -t);      // k*ln2_hi - t
     r = __builtin_fma(kf, 1.90821492927058770002e-10, r);              // + k*ln2_lo  ->  r = -(t - k ln2)
@@ -114,18 +122,65 @@ __device__ __forceinline__ double exp_neg(double t) {
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, -(int)kf);
 }
+__device__ __forceinline__ double exp_neg(double t) {
+    t = fmin(t, 1100.0);
+#if MRA_EXP_VARIANT == 0
+    return exp_neg_poly13(t);
+#elif MRA_EXP_VARIANT == 1
+    const double kf = __builtin_rint(t * 5.7707801635558536296);       // 4 / ln2
+    double r = __builtin_fma(kf, 1.73286795092280954123e-01, -t);      // k*(ln2/4)_hi - t   (hi: 33 bits, exact products)
+    r = __builtin_fma(kf, 4.77053732317646925e-11, r);                 // + k*(ln2/4)_lo
+    double p = 2.7557319223985893e-06;                                  // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 1.388888888888889e-03);
+    p = __builtin_fma(p, r, 8.333333333333333e-03);
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = (int)kf;
+    const double c01 = (ki & 1) ? 8.40896415253714543e-01 : 1.0;       // 2^(-1/4) : 1
+    const double c23 = (ki & 1) ? 5.94603557501360533e-01 : 7.07106781186547524e-01;      // 2^(-3/4) : 2^(-1/2)
+    p *= (ki & 2) ? c23 : c01;
+    return __builtin_amdgcn_ldexp(p, -(ki >> 2));
+#else
+    // this lane's table entry 2^(-lane/64): a pure function of the lane number, hoisted out of every loop by the compiler
+    const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const double tab = exp_neg_poly13((double)lane_ * 1.0830424696249145e-02);      // lane * ln2 / 64
+    const double kf = __builtin_rint(t * 92.332482616893658074);       // 64 / ln2
+    double r = __builtin_fma(kf, 1.08304246932675596327e-02, -t);      // k*(ln2/64)_hi - t
+    r = __builtin_fma(kf, 2.98158582698529328e-12, r);                 // + k*(ln2/64)_lo
+    double p = 8.333333333333333e-03;                                   // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const int ki = (int)kf;
+    const int sel = (ki & 63) << 2;
+    const double tj = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(tab)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(tab)));
+    return __builtin_amdgcn_ldexp(p * tj, -(ki >> 6));
+#endif
+}
 
-// sqrt(x), x >= 0 finite: v_rsq_f64 seed + two Goldschmidt steps (<= 1 ulp)
+// sqrt(x), x >= 0 finite: v_rsq_f64 seed (2^-23 relative), ONE Goldschmidt step (-> 2^-45) and one Newton correction with the
+// residual x - g g (-> rounding level, <= 1 ulp).  (Two Goldschmidt steps before the correction, as until round 3, bought nothing.)
 __device__ __forceinline__ double sqrt_pos(double x) {
     const double y = __builtin_amdgcn_rsq(fmax(x, 1.0e-300));      // x == 0 stays 0 through every step below
     double g = x * y, h = 0.5 * y;
-    double e = __builtin_fma(-h, g, 0.5);
+    const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
     h = __builtin_fma(h, e, h);
-    e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
+#if MRA_EXP_VARIANT == 0
+    {
+        const double e2 = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, e2, g);
+        h = __builtin_fma(h, e2, h);
+    }
+#endif
     // one residual correction: g += (x - g*g) * h
-    h = __builtin_fma(h, e, h);
     const double res = __builtin_fma(-g, g, x);
     return __builtin_fma(res, h, g);
 }

@@ -88,6 +88,9 @@ def main():
                 d["hbm_bytes_per_pass"] = d["hbm_bytes_per_launch"] * d["launches_per_pass"]
                 tot += d["hbm_bytes_per_pass"]
         summary["_whole_pass"] = {"passes_seen": passes, "hbm_bytes_per_pass": tot}
+    # which sources these counters were collected from: bench.py quotes the bytes only while the stamp matches the running tree
+    from csrc_hash import csrc_sha256
+    summary["_collected_from"] = {"csrc_sha256": csrc_sha256(root), "tag": tag}
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_traffic_by_kernel_family.json"), "w"), indent=1)
 
     f = one("sq/*/*_counter_collection.csv")
