@@ -489,6 +489,17 @@ def main():
             lik = tree.getLikelihood(); xP, sdP = tree.predict()
             walls.append(time.perf_counter() - tA)
             tree.plan.close()
+        if os.environ.get("MRA_BENCH_PROFILE_E2E") == "1":     # where the constructor's wall-clock goes, Python side included (stderr)
+            import cProfile
+            import pstats
+            np.random.seed(c["seed"]); make_inputs(c)
+            pr = cProfile.Profile()
+            pr.enable()
+            tree = MRATree(locs, c["r"], cov, y_obs, c["R"], M=c["M"], J=c["J"])
+            lik = tree.getLikelihood(); xP, sdP = tree.predict()
+            pr.disable()
+            tree.plan.close()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
         wall = float(np.median(walls))
         e2e = {"what": "MRATree(locs, r0, cov, y_obs, R, M, J) + getLikelihood() + predict(): host tree replay + uploads + device pass + download",
                "wall_s": wall, "wall_s_all": walls, "value": n_nodes / wall, "unit": "nodes/s",

@@ -99,8 +99,15 @@ struct KernelParams {
 //                      which the compiler hoists to the top of the kernel) and is read with two ds_bpermute_b32 - the LDS
 //                      crossbar, not the FP64 pipe: 12 FP64 instructions
 //   MRA_EXP_VARIANT 1: quarter steps, t = (4 k + j) ln2/4 + r, |r| <= ln2/8, degree 9, 2^(-j/4) by selects: 16 FP64 instructions
+// Measured at C3 (round 4, A/B builds by tools/build_variant.sh): variant 0 IS the fastest - row cascade 1.021 ms against 1.051
+// (variant 1) and 1.058 (variant 2), leaf residual 0.942 against 0.953 / 0.961, pass 5.61 against 5.65 / 5.67 ms.  What the
+// evaluation costs is VALU ISSUE slots, not FP64 operations: the selects, shifts and conversions that pay for a shorter polynomial
+// are instructions too, and the table's register pair pushes the row cascade (255 registers) into 80 B of scratch.
 #ifndef MRA_EXP_VARIANT
-#define MRA_EXP_VARIANT 2
+#define MRA_EXP_VARIANT 0
+#endif
+#ifndef MRA_SQRT_SHORT
+#define MRA_SQRT_SHORT 0
 #endif
 __device__ __forceinline__ double exp_neg_poly13(double t) {
     const double kf = __builtin_rint(t * 1.4426950408889634074);
@@ -165,15 +172,15 @@ __device__ __forceinline__ double exp_neg(double t) {
 #endif
 }
 
-// sqrt(x), x >= 0 finite: v_rsq_f64 seed (2^-23 relative), ONE Goldschmidt step (-> 2^-45) and one Newton correction with the
-// residual x - g g (-> rounding level, <= 1 ulp).  (Two Goldschmidt steps before the correction, as until round 3, bought nothing.)
+// sqrt(x), x >= 0 finite: v_rsq_f64 seed (2^-23 relative), two Goldschmidt steps and one Newton correction with the residual
+// x - g g (<= 1 ulp).  MRA_SQRT_SHORT: ONE Goldschmidt step (-> 2^-45) before the correction (-> rounding level): A/B switch.
 __device__ __forceinline__ double sqrt_pos(double x) {
     const double y = __builtin_amdgcn_rsq(fmax(x, 1.0e-300));      // x == 0 stays 0 through every step below
     double g = x * y, h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
     h = __builtin_fma(h, e, h);
-#if MRA_EXP_VARIANT == 0
+#if !MRA_SQRT_SHORT
     {
         const double e2 = __builtin_fma(-h, g, 0.5);
         g = __builtin_fma(g, e2, g);
@@ -964,6 +971,101 @@ __device__ __forceinline__ double chol16_inv(double a[16], double mr[16], int la
     double lg = 0.5 * log(dsel);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    return lg;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  The same 16 x 16 factorise-and-invert atom, BLOCKED by four columns with the trailing updates on the matrix cores.
+//  chol16_inv above eliminates column by column with the tile row-per-lane (four identical copies in the wave): per column 34 DPP
+//  moves + 16 FMAs + a reciprocal on the dependency chain, 16 times: 3.4 us, the latency atom of every small factorisation
+//  (knot chain, fronts, leaf Cholesky of a shard).  Here the symmetric tile S lives in the MFMA accumulator layout - lane (r, q)
+//  holds S[4 i + q][r], i = 0 .. 3: no replication, 4 doubles per lane - and a panel step p is
+//      B   = S[4p .. 4p+3, 4p .. 4p+3]                 10 numbers, fetched to every lane with v_readlane (uniform values)
+//      B   = U D U^T, Linv = D^-1/2 U^-1                4 x 4, every lane the same arithmetic: three reciprocals on the chain,
+//                                                       the square roots beside it
+//      Y   = Linv S[4p .. 4p+3, :]                      ONE v_mfma_f64_16x16x4: A = Linv (rows 0 .. 3 of a zero-padded operand),
+//                                                       B = register p of S; Y[q][r] = L[r][4p + q] lands in register 0 of lane (r, q)
+//      S  -= Y^T Y                                      ONE v_mfma: lane (r, q) supplies Y[q][r] as A[m = r][k = q] AND as B[k = q][n = r]
+//  and the inverse is carried along on the identity, M <- E_p M, two more MFMAs per panel off the critical path:
+//      M[4p .. 4p+3, :] = Linv M[4p .. 4p+3, :],    M[rows below] -= L[rows below, panel] M[4p .. 4p+3, :].
+//  The symmetry of S is what makes register p serve as both the panel (A operand) and its transpose (B operand) without a
+//  single cross-lane move.  Results go to LDS row-major (L lower triangle, L^-1 lower triangle); returns sum(log diag L).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /* LDS, 16 x 16 row-major, lower triangle valid */,
+                                              double* __restrict__ Lout, double* __restrict__ Iout /* LDS 16 x 16 row-major each */,
+                                              int lane, bool& bad) {
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 15, q = lane >> 4;
+    d4 s, m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + q;
+        s[i] = row >= r ? tile[row * 16 + r] : tile[r * 16 + row];
+        m[i] = row == r ? 1.0 : 0.0;
+    }
+    double dsel = 1.0;
+    double lcol[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        // ---- the diagonal block, uniform: b[a][c] = S[4p + a][4p + c] sits in lane (r = 4p + c, q = a), register p
+        double b[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) b[a][c] = readlane_f64(s[p], (4 * p + c) + 16 * a);
+        // ---- B = U D U^T (unit lower U), reciprocals of the pivots on the chain, square roots beside it
+        double d0 = b[0][0];
+        if (!(d0 > 0.0)) { bad = true; d0 = 1.0; }
+        const double i0 = rcp_pos(d0);
+        const double u10 = b[1][0] * i0, u20 = b[2][0] * i0, u30 = b[3][0] * i0;
+        double d1 = __builtin_fma(-u10, b[1][0], b[1][1]);
+        if (!(d1 > 0.0)) { bad = true; d1 = 1.0; }
+        const double i1 = rcp_pos(d1);
+        const double c21 = __builtin_fma(-u20, b[1][0], b[2][1]), c31 = __builtin_fma(-u30, b[1][0], b[3][1]);
+        const double u21 = c21 * i1, u31 = c31 * i1;
+        double d2 = __builtin_fma(-u21, c21, __builtin_fma(-u20, b[2][0], b[2][2]));
+        if (!(d2 > 0.0)) { bad = true; d2 = 1.0; }
+        const double i2 = rcp_pos(d2);
+        const double c32 = __builtin_fma(-u31, c21, __builtin_fma(-u30, b[2][0], b[3][2]));
+        const double u32 = c32 * i2;
+        double d3 = __builtin_fma(-u32, c32, __builtin_fma(-u31, c31, __builtin_fma(-u30, b[3][0], b[3][3])));
+        if (!(d3 > 0.0)) { bad = true; d3 = 1.0; }
+        const double rs0 = rsqrt_pos(d0), rs1 = rsqrt_pos(d1), rs2 = rsqrt_pos(d2), rs3 = rsqrt_pos(d3);
+        // U^-1 (unit lower)
+        const double v10 = -u10, v21 = -u21, v32 = -u32;
+        const double v20 = __builtin_fma(u21, u10, -u20), v31 = __builtin_fma(u32, u21, -u31);
+        const double v30 = -__builtin_fma(u32, v20, __builtin_fma(u31, v10, u30));
+        // ---- this lane's element of the zero-padded A operand: Linv[r][q] = rs_r v_rq for q <= r < 4
+        const double vr = (r == 0) ? 1.0 : (r == 1) ? (q == 0 ? v10 : 1.0) : (r == 2) ? (q == 0 ? v20 : (q == 1 ? v21 : 1.0)) : (q == 0 ? v30 : (q == 1 ? v31 : (q == 2 ? v32 : 1.0)));
+        const double rsr = (r == 0) ? rs0 : (r == 1) ? rs1 : (r == 2) ? rs2 : rs3;
+        const double la = (r < 4 && q <= r) ? rsr * vr : 0.0;
+        const d4 zero = {0, 0, 0, 0};
+        // ---- Y = Linv S[panel rows, :]; the rows of the panel and above are finished: only columns r >= 4p carry the factor
+        const d4 yy = mfma16(la, s[p], zero);
+        const double y = (r >= 4 * p) ? yy[0] : 0.0;
+        lcol[p] = (r >= 4 * p + q) ? y : 0.0;                 // L[r][4p + q]
+        // ---- S -= Y^T Y (the finished rows / columns are not looked at again)
+        if (p < 3) s = mfma16(-y, y, s);
+        // ---- the inverse: M[panel rows] = Linv M[panel rows]; rows below -= L[below, panel] M[panel rows]
+        const d4 mp = mfma16(la, m[p], zero);
+        m[p] = mp[0];
+        if (p < 3) {
+            const double yb = (r >= 4 * p + 4) ? y : 0.0;     // (zero rows of the A operand leave the panel rows and everything above alone)
+            m = mfma16(-yb, mp[0], m);
+        }
+        dsel = (r == 4 * p) ? d0 : (r == 4 * p + 1) ? d1 : (r == 4 * p + 2) ? d2 : (r == 4 * p + 3) ? d3 : dsel;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        Lout[r * 16 + 4 * p + q] = lcol[p];
+        Iout[(4 * p + q) * 16 + r] = (4 * p + q >= r) ? m[p] : 0.0;
+    }
+    double lg = (q == 0) ? 0.5 * log(dsel) : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
     return lg;
 }
 

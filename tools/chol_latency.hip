@@ -25,6 +25,25 @@ __global__ __launch_bounds__(64) void k_c16(double* out, int iters) {
     out[threadIdx.x] = acc + (bad ? 1 : 0);
 }
 
+// the blocked atom (chol16_mfma): same dependent-call timing, and a correctness dump of L and L^-1 for one tile
+__global__ __launch_bounds__(64) void k_c16m(double* out, int iters, const double* tile_in, double* Lres, double* Ires) {
+    __shared__ __attribute__((aligned(16))) double st[256], sl[256], si[256];
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < 256; e += 64) st[e] = tile_in[e];
+    __syncthreads();
+    double acc = 0;
+    bool bad = false;
+    for (int it = 0; it < iters; ++it) {
+        const double lg = chol16_mfma(st, sl, si, lane, bad);
+        lds_wave_sync();
+        acc += lg + si[3 * 16 + 1] + sl[2 * 16 + 1];
+        if (lane == 0) st[15 * 16 + 15] += 1e-30 * acc;      // keep the calls dependent
+        lds_wave_sync();
+    }
+    for (int e = lane; e < 256; e += 64) { Lres[e] = sl[e]; Ires[e] = si[e]; }
+    out[threadIdx.x] = acc + (bad ? 1 : 0);
+}
+
 __global__ __launch_bounds__(64) void k_mfma_chain(double* out, int iters) {
     d4 acc = {0, 0, 0, 0};
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0;
@@ -41,6 +60,41 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1);
     }
     printf("chol16_inv: %.3f us per call (one wave, dependent calls)\n", ms * 1e3 / 2000);
+    {
+        // a well-conditioned and a badly scaled SPD tile: L and L^-1 against a host factorisation
+        for (int which = 0; which < 2; ++which) {
+            double T[256], Lh[256] = {0}, Ih[256] = {0};
+            for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+                const double sc = which ? pow(10.0, (i % 5) - 2.0) * pow(10.0, (j % 5) - 2.0) : 1.0;
+                T[i * 16 + j] = sc * ((i == j ? 1.5 : 0.0) + exp(-0.3 * fabs((double)i - j)));
+            }
+            for (int j = 0; j < 16; ++j) {
+                double d = T[j * 16 + j];
+                for (int k = 0; k < j; ++k) d -= Lh[j * 16 + k] * Lh[j * 16 + k];
+                Lh[j * 16 + j] = sqrt(d);
+                for (int i = j + 1; i < 16; ++i) { double v = T[i * 16 + j]; for (int k = 0; k < j; ++k) v -= Lh[i * 16 + k] * Lh[j * 16 + k]; Lh[i * 16 + j] = v / Lh[j * 16 + j]; }
+            }
+            for (int c = 0; c < 16; ++c) for (int i = c; i < 16; ++i) {
+                double v = (i == c) ? 1.0 : 0.0;
+                for (int k = c; k < i; ++k) v -= Lh[i * 16 + k] * Ih[k * 16 + c];
+                Ih[i * 16 + c] = v / Lh[i * 16 + i];
+            }
+            double *dT, *dL, *dI; hipMalloc(&dT, 2048); hipMalloc(&dL, 2048); hipMalloc(&dI, 2048);
+            hipMemcpy(dT, T, 2048, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_c16m, dim3(1), dim3(64), 0, 0, dout, 1, dT, dL, dI);
+            double Lg[256], Ig[256], o0; hipMemcpy(Lg, dL, 2048, hipMemcpyDeviceToHost); hipMemcpy(Ig, dI, 2048, hipMemcpyDeviceToHost); hipMemcpy(&o0, dout, 8, hipMemcpyDeviceToHost);
+            double eL = 0, eI = 0, lgh = 0;
+            for (int i = 0; i < 16; ++i) lgh += log(Lh[i * 16 + i]);
+            for (int e = 0; e < 256; ++e) { eL = fmax(eL, fabs(Lg[e] - Lh[e]) / (fabs(Lh[e]) + 1e-300 + (Lh[e] == 0))); eI = fmax(eI, fabs(Ig[e] - Ih[e]) / (fabs(Ih[e]) + (Ih[e] == 0))); }
+            printf("chol16_mfma tile %d: max rel err L %.2e, L^-1 %.2e; sum log diag host %.15g\n", which, eL, eI, lgh);
+            if (which == 0)
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipEventRecord(e0); hipLaunchKernelGGL(k_c16m, dim3(1), dim3(64), 0, 0, dout, 2000, dT, dL, dI); hipEventRecord(e1); hipEventSynchronize(e1);
+                    hipEventElapsedTime(&ms, e0, e1);
+                }
+        }
+        printf("chol16_mfma: %.3f us per call (one wave, dependent calls, tile and results through LDS)\n", ms * 1e3 / 2000);
+    }
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0); hipLaunchKernelGGL(k_mfma_chain, dim3(1), dim3(64), 0, 0, dout, 100000); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
