@@ -105,7 +105,7 @@ class MRATree(object):
             # the reference indexes a non-float R as a matrix (MRANode.py:85-88) and fails on an int
             raise TypeError("R must be a Python float (scalar nugget variance); got %r" % type(R))
         obs_arr = np.asarray(obs, dtype=np.float64)
-        self.obs_inds = np.where(np.logical_not(np.isnan(obs_arr)))[0]
+        self._obs_inds = None                   # (the reference's obs_inds, MRATree.py:62: computed when somebody reads it)
         self.obs, self.R = obs_arr, R
 
         spec = probe_cov(cov, self.d, np.asarray(locs, dtype=np.float64))
@@ -140,6 +140,12 @@ class MRATree(object):
             mean, var = None, None
         self.root = RootView(d, u, mean, var, N, self.topology, np.asarray(locs, dtype=np.float64), spec)
         self._node_blocks = {}
+
+    @property
+    def obs_inds(self):
+        if self._obs_inds is None:
+            self._obs_inds = np.where(np.logical_not(np.isnan(self.obs)))[0]
+        return self._obs_inds
 
     def getLikelihood(self):
         return self.root.d + self.root.u

@@ -994,6 +994,7 @@ __device__ __forceinline__ double chol16_inv(double a[16], double mr[16], int la
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
+template <int ABL = 0>      // ABL: ablation bits for the timing lab (tools/chol_latency.hip) only - wrong results; 0 everywhere else
 __device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /* LDS, 16 x 16 row-major, lower triangle valid */,
                                               double* __restrict__ Lout, double* __restrict__ Iout /* LDS 16 x 16 row-major each */,
                                               int lane, bool& bad) {
@@ -1015,25 +1016,29 @@ __device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /*
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int c = 0; c <= a; ++c) b[a][c] = readlane_f64(s[p], (4 * p + c) + 16 * a);
+            for (int c = 0; c <= a; ++c) b[a][c] = (ABL & 16) ? s[p] + (double)(a + c) : readlane_f64(s[p], (4 * p + c) + 16 * a);
         // ---- B = U D U^T (unit lower U), reciprocals of the pivots on the chain, square roots beside it
         double d0 = b[0][0];
         if (!(d0 > 0.0)) { bad = true; d0 = 1.0; }
-        const double i0 = rcp_pos(d0);
+#define MRA_ATOM_RCP(x) ((ABL & 2) ? __builtin_amdgcn_rcp(x) : rcp_pos(x))
+#define MRA_ATOM_RSQ(x) ((ABL & 4) ? __builtin_amdgcn_rsq(x) : rsqrt_pos(x))
+        const double i0 = MRA_ATOM_RCP(d0);
         const double u10 = b[1][0] * i0, u20 = b[2][0] * i0, u30 = b[3][0] * i0;
         double d1 = __builtin_fma(-u10, b[1][0], b[1][1]);
         if (!(d1 > 0.0)) { bad = true; d1 = 1.0; }
-        const double i1 = rcp_pos(d1);
+        const double i1 = MRA_ATOM_RCP(d1);
         const double c21 = __builtin_fma(-u20, b[1][0], b[2][1]), c31 = __builtin_fma(-u30, b[1][0], b[3][1]);
         const double u21 = c21 * i1, u31 = c31 * i1;
         double d2 = __builtin_fma(-u21, c21, __builtin_fma(-u20, b[2][0], b[2][2]));
         if (!(d2 > 0.0)) { bad = true; d2 = 1.0; }
-        const double i2 = rcp_pos(d2);
+        const double i2 = MRA_ATOM_RCP(d2);
         const double c32 = __builtin_fma(-u31, c21, __builtin_fma(-u30, b[2][0], b[3][2]));
         const double u32 = c32 * i2;
         double d3 = __builtin_fma(-u32, c32, __builtin_fma(-u31, c31, __builtin_fma(-u30, b[3][0], b[3][3])));
         if (!(d3 > 0.0)) { bad = true; d3 = 1.0; }
-        const double rs0 = rsqrt_pos(d0), rs1 = rsqrt_pos(d1), rs2 = rsqrt_pos(d2), rs3 = rsqrt_pos(d3);
+        const double rs0 = MRA_ATOM_RSQ(d0), rs1 = MRA_ATOM_RSQ(d1), rs2 = MRA_ATOM_RSQ(d2), rs3 = MRA_ATOM_RSQ(d3);
+#undef MRA_ATOM_RCP
+#undef MRA_ATOM_RSQ
         // U^-1 (unit lower)
         const double v10 = -u10, v21 = -u21, v32 = -u32;
         const double v20 = __builtin_fma(u21, u10, -u20), v31 = __builtin_fma(u32, u21, -u31);
@@ -1050,11 +1055,13 @@ __device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /*
         // ---- S -= Y^T Y (the finished rows / columns are not looked at again)
         if (p < 3) s = mfma16(-y, y, s);
         // ---- the inverse: M[panel rows] = Linv M[panel rows]; rows below -= L[below, panel] M[panel rows]
-        const d4 mp = mfma16(la, m[p], zero);
-        m[p] = mp[0];
-        if (p < 3) {
-            const double yb = (r >= 4 * p + 4) ? y : 0.0;     // (zero rows of the A operand leave the panel rows and everything above alone)
-            m = mfma16(-yb, mp[0], m);
+        if (!(ABL & 1)) {
+            const d4 mp = mfma16(la, m[p], zero);
+            m[p] = mp[0];
+            if (p < 3) {
+                const double yb = (r >= 4 * p + 4) ? y : 0.0;     // (zero rows of the A operand leave the panel rows and everything above alone)
+                m = mfma16(-yb, mp[0], m);
+            }
         }
         dsel = (r == 4 * p) ? d0 : (r == 4 * p + 1) ? d1 : (r == 4 * p + 2) ? d2 : (r == 4 * p + 3) ? d3 : dsel;
     }
@@ -1063,6 +1070,7 @@ __device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /*
         Lout[r * 16 + 4 * p + q] = lcol[p];
         Iout[(4 * p + q) * 16 + r] = (4 * p + q >= r) ? m[p] : 0.0;
     }
+    if (ABL & 8) return dsel;
     double lg = (q == 0) ? 0.5 * log(dsel) : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);

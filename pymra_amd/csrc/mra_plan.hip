@@ -23,7 +23,7 @@ struct PlanTrace {
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     explicit PlanTrace(const char* w) : on(getenv("MRA_TRACE_PLAN") != nullptr), t0(now()), last(t0), what(w) {}
     void mark(const char* label) { if (on) { const double t = now(); fprintf(stderr, "  [%s] %-34s %7.2f ms\n", what, label, t - last); last = t; } }
-    ~PlanTrace() { if (on) fprintf(stderr, "  [%s] total %.2f ms\n", what, now() - t0); }
+    ~PlanTrace() { if (on) fprintf(stderr, "  [%s] total %.2f ms (descriptor uploads of this thread so far: %ld, %.2f ms)\n", what, now() - t0, upload_stats().n, upload_stats().ms); }
 };
 }  // namespace
 
@@ -112,7 +112,7 @@ hipError_t mraFree(void* p) {
 // ---- stream cache: creating the two prioritised streams of a plan costs milliseconds (each is a hardware queue), destroying them
 // as much; a process that builds a new MRATree per objective call (README.md:96-104) gets the pair of the previous plan back
 namespace {
-struct StreamPair { hipStream_t hi, lo; double* host_res; double* host_res_dev; };      // + the pinned, device-mapped result record
+struct StreamPair { hipStream_t hi, lo; double* host_res; double* host_res_dev; char* arena_host; };      // + the pinned result record and the pinned mirror of the descriptor arena
 std::mutex g_streams_mu;
 std::multimap<int, StreamPair> g_streams;                           // device -> idle pair (both synchronised when they were returned)
 }  // namespace
@@ -122,6 +122,7 @@ static void acquire_streams(mra_plan* pl) {
         auto it = g_streams.find(pl->device);
         if (it != g_streams.end()) {
             pl->stream = it->second.hi; pl->stream2 = it->second.lo; pl->host_res = it->second.host_res; pl->host_res_dev = it->second.host_res_dev;
+            pl->arena.host = it->second.arena_host;
             g_streams.erase(it);
             return;
         }
@@ -137,10 +138,11 @@ static void return_streams(mra_plan* pl) {
         if (pl->stream2) hipStreamDestroy(pl->stream2);
     } else {
         std::lock_guard<std::mutex> lock(g_streams_mu);
-        if (g_streams.count(pl->device) < 4) { g_streams.insert({pl->device, StreamPair{pl->stream, pl->stream2, pl->host_res, pl->host_res_dev}}); pl->host_res = nullptr; }
+        if (g_streams.count(pl->device) < 4) { g_streams.insert({pl->device, StreamPair{pl->stream, pl->stream2, pl->host_res, pl->host_res_dev, pl->arena.host}}); pl->host_res = nullptr; pl->arena.host = nullptr; }
         else { hipStreamDestroy(pl->stream); hipStreamDestroy(pl->stream2); }
     }
     if (pl->host_res) hipHostFree(pl->host_res);
+    if (pl->arena.host) { hipHostFree(pl->arena.host); pl->arena.host = nullptr; }
     pl->host_res = pl->host_res_dev = nullptr;
     pl->stream = pl->stream2 = nullptr;
 }
@@ -153,6 +155,24 @@ static void parallel_rows(int64_t n, F fn, int64_t min_per_thread = 65536) {
     std::vector<std::thread> pool;
     for (int t = 0; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
     for (auto& th : pool) th.join();
+}
+
+// the plan's descriptor arena: a 16 MB device block (from the block cache) and its pinned mirror (kept with the stream pair)
+static void init_arena(mra_plan* pl) {
+    UploadArena& a = pl->arena;
+    a.cap = (size_t)16 << 20;
+    a.used = a.flushed = 0;
+    if (mraMalloc((void**)&a.dev, a.cap) != hipSuccess) { a.dev = nullptr; a.cap = 0; return; }       // no arena: stand-alone uploads
+    if (!a.host) {
+        if (g_dry) a.host = (char*)malloc(a.cap);
+        else if (hipHostMalloc((void**)&a.host, a.cap, hipHostMallocDefault) != hipSuccess) a.host = nullptr;
+    }
+    if (!a.host) { mraFree(a.dev); a.dev = nullptr; a.cap = 0; }
+}
+static void drop_arena(mra_plan* pl) {
+    if (pl->arena.dev) mraFree(pl->arena.dev);
+    pl->arena.dev = nullptr;
+    if (g_dry && pl->arena.host) { free(pl->arena.host); pl->arena.host = nullptr; }
 }
 
 static void derive_kernel_params(KernelParams& kp) {
@@ -181,6 +201,7 @@ static void fill_knot_arrays(mra_plan* pl);
 // ------------------------------------------------------------------------------------------------
 static void build_static(mra_plan* pl) {
     PlanTrace tr("build_static");
+    ArenaScope arena(&pl->arena);
     const int L = pl->n_levels;
     pl->Ka = 0;
     for (int m = 0; m < L; ++m) {
@@ -618,6 +639,8 @@ static void build_static(mra_plan* pl) {
         }
         tr.mark("row tiles of the cascades");
     }
+    arena.finish();
+    tr.mark("descriptor arena to the device");
     if (!pl->knots_pending) { fill_knot_arrays(pl); tr.mark("knot arrays"); }
 }
 
@@ -653,6 +676,7 @@ static void fill_knot_arrays(mra_plan* pl) {
 // leaf descriptors: depend on which rows are observed
 static void build_leaf(mra_plan* pl, const double* y) {
     PlanTrace tr("build_leaf");
+    ArenaScope arena(&pl->arena);
     const size_t nl = pl->leaf_nodes.size();
     pl->cphantom_valid = false;
     pl->leaf_nop.assign(nl, 0);
@@ -1029,6 +1053,8 @@ static void build_leaf(mra_plan* pl, const double* y) {
             pl->leaf_solve_ok = pl->n_trsm_small > 0 && nat_max <= 13 && nat_max > 0 && pl->leaf_solve_lds <= 160 * 1024 && pl->leaf_max_rows >= 128;
         }
     }
+    arena.finish();
+    tr.mark("descriptor arena to the device");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1821,16 +1847,19 @@ int mra_plan_create(mra_plan** out, const mra_topology* t, int device) {
         }
         for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
         tr.mark("streams, events");
+        init_arena(pl);
         build_static(pl);
         *out = pl;
         return MRA_OK;
     } catch (const MraError& e) {
         int rc = fail(nullptr, e);
+        if (pl) drop_arena(pl);
         if (pl && !g_dry) return_streams(pl);
         delete pl;
         return rc;
     } catch (const std::exception& e) {
         g_last_error = e.what();
+        if (pl) drop_arena(pl);
         if (pl && !g_dry) return_streams(pl);
         delete pl;
         return MRA_ERR_INVALID;
@@ -1849,7 +1878,8 @@ int mra_plan_destroy(mra_plan* pl) {
     if (pl->stream) hipStreamSynchronize(pl->stream);
     if (pl->stream2) hipStreamSynchronize(pl->stream2);
     for (int k = 0; k < 6; ++k) if (pl->ev[k]) hipEventDestroy(pl->ev[k]);
-    return_streams(pl);                              // (with the pinned result record)
+    drop_arena(pl);
+    return_streams(pl);                              // (with the pinned result record and the arena's pinned mirror)
     if (pl->ev_fork) hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) hipEventDestroy(pl->ev_join);
     delete pl;
@@ -1861,7 +1891,7 @@ int mra_release_cached_memory(void) {
     if (g_dry) return MRA_OK;
     {
         std::lock_guard<std::mutex> lock(g_streams_mu);
-        for (auto& e : g_streams) { hipStreamDestroy(e.second.hi); hipStreamDestroy(e.second.lo); if (e.second.host_res) hipHostFree(e.second.host_res); }
+        for (auto& e : g_streams) { hipStreamDestroy(e.second.hi); hipStreamDestroy(e.second.lo); if (e.second.host_res) hipHostFree(e.second.host_res); if (e.second.arena_host) hipHostFree(e.second.arena_host); }
         g_streams.clear();
     }
     {
@@ -2360,36 +2390,45 @@ void replay_plan_hook(void* user, const mra_topo::Result& t) {
         }
         for (int k = 0; k < 6 && !g_dry; ++k) HIP_TRY(hipEventCreate(&pl->ev[k]));
         tr.mark("copies of the topology, streams, events");
-        build_static(pl);
-        tr.mark("build_static");
+        init_arena(pl);
         const int64_t* src = t.ext_perm ? t.ext_src : t.src.data();
         const int64_t* perm = t.ext_perm ? t.ext_perm : t.perm.data();
-        {
-            std::lock_guard<std::mutex> lock(g_stage_mutex);
-            double* xp = stage_buffer((size_t)pl->P * 3);
-            double* yp = xp + (size_t)pl->P * 2;
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        double* xp = stage_buffer((size_t)pl->P * 3);
+        double* yp = xp + (size_t)pl->P * 2;
+        // the gather of locations and observations into leaf order runs beside build_static (neither needs the other)
+        const long P = pl->P;
+        bool gather_failed = false;
+        std::thread gather([&, P]() {
             const double nan = std::nan("");
             const double* locs = c.locs; const double* y = c.y;
-            parallel_rows(pl->P, [&](int64_t a, int64_t b) {
-                for (int64_t p = a; p < b; ++p) {
-                    const int64_t q = src[p];
-                    xp[2 * p] = locs[2 * q]; xp[2 * p + 1] = locs[2 * q + 1];
-                    yp[p] = perm[p] < 0 ? nan : y[q];
-                }
-            });
-            tr.mark("gather locations and observations");
-            int rc = mra_plan_set_locs(pl, xp);
-            if (rc == MRA_OK) rc = mra_plan_set_obs(pl, yp, c.R);
-            if (rc != MRA_OK) throw MraError(rc, pl->err);
-            tr.mark("uploads, leaf descriptors");
-        }
+            try {
+                parallel_rows(P, [&](int64_t a, int64_t b) {
+                    for (int64_t p = a; p < b; ++p) {
+                        const int64_t q = src[p];
+                        xp[2 * p] = locs[2 * q]; xp[2 * p + 1] = locs[2 * q + 1];
+                        yp[p] = perm[p] < 0 ? nan : y[q];
+                    }
+                });
+            } catch (...) { gather_failed = true; }
+        });
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{gather};
+        build_static(pl);
+        tr.mark("build_static");
+        gather.join();
+        if (gather_failed) throw MraError(MRA_ERR_INVALID, "gathering locations / observations failed (thread creation)");
+        tr.mark("(gather of locations and observations: beside it)");
+        int rc = mra_plan_set_locs(pl, xp);
+        if (rc == MRA_OK) rc = mra_plan_set_obs(pl, yp, c.R);
+        if (rc != MRA_OK) throw MraError(rc, pl->err);
+        tr.mark("uploads, leaf descriptors");
         c.pl = pl;
     } catch (const MraError& e) {
         c.rc = e.code; c.err = e.msg;
-        if (pl) { if (!g_dry) return_streams(pl); delete pl; }
+        if (pl) { drop_arena(pl); if (!g_dry) return_streams(pl); delete pl; }
     } catch (const std::exception& e) {
         c.rc = MRA_ERR_INVALID; c.err = e.what();
-        if (pl) { if (!g_dry) return_streams(pl); delete pl; }
+        if (pl) { drop_arena(pl); if (!g_dry) return_streams(pl); delete pl; }
     }
 }
 }  // namespace

@@ -16,6 +16,7 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <time.h>
 
 #define MRA_VERSION_STR "mra_hip 0.2 (gfx950)"
 
@@ -116,17 +117,64 @@ struct Work {
     Work with_bytes(double b) const { Work w = *this; w.bytes = b; return w; }
 };
 
+// (MRA_TRACE_PLAN: number of descriptor uploads and the time spent in them)
+struct UploadStats { long n = 0; double ms = 0; };
+inline UploadStats& upload_stats() { static thread_local UploadStats s; return s; }
+
+// Descriptor arena: a plan uploads ~170 small arrays (problem descriptors, index lists) while it is built - each one a device
+// allocation and a synchronous pageable copy, ~20 us apiece, a third of the construction time of a 1024^2 tree.  Inside an
+// ArenaScope the small ones (< 256 KB) are bump-allocated from ONE device block of the plan and staged in a pinned host mirror;
+// the scope's end sends what was added in one copy.  Pointers are final at once (descriptors embed each other's addresses).
+// A full arena simply falls back to the stand-alone path.
+struct UploadArena {
+    char* dev = nullptr;
+    char* host = nullptr;           // pinned mirror (plain memory in a host dry run)
+    size_t cap = 0, used = 0, flushed = 0;
+    static constexpr size_t SMALL = 256 * 1024;
+    void* take(size_t bytes, const void* src) {
+        const size_t at = (used + 255) & ~(size_t)255;
+        if (!dev || at + bytes > cap) return nullptr;
+        memcpy(host + at, src, bytes);
+        used = at + bytes;
+        return dev + at;
+    }
+    void flush() {
+        if (used > flushed) {
+            if (mraMemcpy(dev + flushed, host + flushed, used - flushed, hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed (descriptor arena)");
+            flushed = used;
+        }
+    }
+};
+inline UploadArena*& current_arena() { static thread_local UploadArena* a = nullptr; return a; }
+struct ArenaScope {
+    UploadArena* prev;
+    UploadArena* mine;
+    explicit ArenaScope(UploadArena* a) : prev(current_arena()), mine(a) { current_arena() = a; }
+    void finish() { current_arena() = prev; if (mine) { UploadArena* a = mine; mine = nullptr; a->flush(); } }
+    ~ArenaScope() { current_arena() = prev; if (mine) { try { mine->flush(); } catch (...) {} } }      // (error paths: the plan is torn down anyway)
+};
+
 template <class T>
 struct DevVec {
     T* p = nullptr;
     size_t n = 0;
+    bool in_arena = false;          // p points into the plan's descriptor arena: nothing to free
     void upload(const std::vector<T>& h) {
+        static const bool trace = getenv("MRA_TRACE_PLAN") != nullptr;
+        timespec t0{}, t1{};
+        if (trace) clock_gettime(CLOCK_MONOTONIC, &t0);
         release();
         n = h.size();
         if (n) {
-            if (mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
-            if (mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
+            UploadArena* a = current_arena();
+            void* q = (a && n * sizeof(T) < UploadArena::SMALL) ? a->take(n * sizeof(T), h.data()) : nullptr;
+            if (q) { p = (T*)q; in_arena = true; }
+            else {
+                if (mraMalloc((void**)&p, n * sizeof(T)) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMalloc failed (descriptor array)");
+                if (mraMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) throw MraError(MRA_ERR_HIP, "hipMemcpy H2D failed");
+            }
         }
+        if (trace) { clock_gettime(CLOCK_MONOTONIC, &t1); upload_stats().n += 1; upload_stats().ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6; }
     }
     // copy into the EXISTING allocation (descriptors already point into it)
     void fill(const std::vector<T>& h) {
@@ -144,9 +192,10 @@ struct DevVec {
         }
     }
     void release() {
-        if (p) mraFree(p);
+        if (p && !in_arena) mraFree(p);
         p = nullptr;
         n = 0;
+        in_arena = false;
     }
     ~DevVec() { release(); }
 };
@@ -177,6 +226,7 @@ struct LevelData {
 
 struct mra_plan {
     int device = 0;
+    UploadArena arena;                   // the small descriptor arrays of this plan (device block + pinned mirror, see UploadArena)
     hipStream_t stream = nullptr;        // the pass; carries the chain of small dependent launches and the all-reduce (high priority)
     hipStream_t stream2 = nullptr;       // side stream: the leaf update runs here, beside the front chain / all-reduce (low priority)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void k_c16(double* out, int iters) {
 }
 
 // the blocked atom (chol16_mfma): same dependent-call timing, and a correctness dump of L and L^-1 for one tile
-__global__ __launch_bounds__(64) void k_c16m(double* out, int iters, const double* tile_in, double* Lres, double* Ires) {
+template <int ABL>
+__global__ __launch_bounds__(256) void k_c16m(double* out, int iters, const double* tile_in, double* Lres, double* Ires) {
     __shared__ __attribute__((aligned(16))) double st[256], sl[256], si[256];
     const int lane = threadIdx.x & 63;
     for (int e = lane; e < 256; e += 64) st[e] = tile_in[e];
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(64) void k_c16m(double* out, int iters, const doubl
     double acc = 0;
     bool bad = false;
     for (int it = 0; it < iters; ++it) {
-        const double lg = chol16_mfma(st, sl, si, lane, bad);
+        const double lg = chol16_mfma<ABL>(st, sl, si, lane, bad);
         lds_wave_sync();
         acc += lg + si[3 * 16 + 1] + sl[2 * 16 + 1];
         if (lane == 0) st[15 * 16 + 15] += 1e-30 * acc;      // keep the calls dependent
@@ -49,6 +50,28 @@ __global__ __launch_bounds__(64) void k_mfma_chain(double* out, int iters) {
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0;
     for (int it = 0; it < iters; ++it) acc = mfma16(a, b, acc);
     out[threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+// dependent-chain latencies of the instructions the atom is made of (cycles from s_memtime, one wave)
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_lat(double* out, long long* cyc, int iters) {
+    double x = 1.0 + threadIdx.x * 1e-3, y = 0.999;
+    d4 acc = {x, x, x, x};
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (WHAT == 0) { x = __builtin_fma(x, y, 1e-3); x = __builtin_fma(x, y, 1e-3); x = __builtin_fma(x, y, 1e-3); x = __builtin_fma(x, y, 1e-3); }
+        if (WHAT == 1) { x = __builtin_amdgcn_rcp(x); x = __builtin_amdgcn_rcp(x); x = __builtin_amdgcn_rcp(x); x = __builtin_amdgcn_rcp(x); }
+        if (WHAT == 2) { x = rcp_pos(x); x = rcp_pos(x); x = rcp_pos(x); x = rcp_pos(x); }
+        if (WHAT == 3) { x = rsqrt_pos(x); x = rsqrt_pos(x); x = rsqrt_pos(x); x = rsqrt_pos(x); }
+        if (WHAT == 4) { for (int k = 0; k < 4; ++k) x = __builtin_fma(readlane_f64(x, 17), y, 1e-3); }
+        if (WHAT == 5) { for (int k = 0; k < 4; ++k) acc = mfma16(acc[0], y, acc); }
+        if (WHAT == 6) { for (int k = 0; k < 4; ++k) { acc = mfma16(x, y, acc); x = __builtin_fma(acc[0], y, 1e-3); } }
+        if (WHAT == 7) { for (int k = 0; k < 4; ++k) x = __builtin_fma(row_bcast(x, 3), y, 1e-3); }
+        if (WHAT == 8) { for (int k = 0; k < 4; ++k) x = __hiloint2double(__builtin_amdgcn_ds_bpermute(68, __double2hiint(x)), __builtin_amdgcn_ds_bpermute(68, __double2loint(x))) * y; }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x] = x + acc[0] + acc[1];
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
 int main() {
@@ -81,25 +104,39 @@ int main() {
             }
             double *dT, *dL, *dI; hipMalloc(&dT, 2048); hipMalloc(&dL, 2048); hipMalloc(&dI, 2048);
             hipMemcpy(dT, T, 2048, hipMemcpyHostToDevice);
-            hipLaunchKernelGGL(k_c16m, dim3(1), dim3(64), 0, 0, dout, 1, dT, dL, dI);
+            hipLaunchKernelGGL(k_c16m<0>, dim3(1), dim3(64), 0, 0, dout, 1, dT, dL, dI);
             double Lg[256], Ig[256], o0; hipMemcpy(Lg, dL, 2048, hipMemcpyDeviceToHost); hipMemcpy(Ig, dI, 2048, hipMemcpyDeviceToHost); hipMemcpy(&o0, dout, 8, hipMemcpyDeviceToHost);
             double eL = 0, eI = 0, lgh = 0;
             for (int i = 0; i < 16; ++i) lgh += log(Lh[i * 16 + i]);
             for (int e = 0; e < 256; ++e) { eL = fmax(eL, fabs(Lg[e] - Lh[e]) / (fabs(Lh[e]) + 1e-300 + (Lh[e] == 0))); eI = fmax(eI, fabs(Ig[e] - Ih[e]) / (fabs(Ih[e]) + (Ih[e] == 0))); }
             printf("chol16_mfma tile %d: max rel err L %.2e, L^-1 %.2e; sum log diag host %.15g\n", which, eL, eI, lgh);
-            if (which == 0)
-                for (int rep = 0; rep < 2; ++rep) {
-                    hipEventRecord(e0); hipLaunchKernelGGL(k_c16m, dim3(1), dim3(64), 0, 0, dout, 2000, dT, dL, dI); hipEventRecord(e1); hipEventSynchronize(e1);
-                    hipEventElapsedTime(&ms, e0, e1);
-                }
+            if (which == 0) {
+#define TIME_ABL(A, label) do { for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL(k_c16m<A>, dim3(1), dim3(64), 0, 0, dout, 2000, dT, dL, dI); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } \
+                printf("chol16_mfma<%2d> %-52s %.3f us per call\n", A, label, ms * 1e3 / 2000); } while (0)
+                TIME_ABL(0, "(full; one wave, dependent calls, tile/results via LDS)");
+                TIME_ABL(1, "without the inverse's MFMAs");
+                TIME_ABL(8, "without the log + reduction");
+                TIME_ABL(9, "without inverse and log");
+                TIME_ABL(11, "... and bare v_rcp_f64 instead of rcp_pos");
+                TIME_ABL(15, "... and bare v_rsq_f64 instead of rsqrt_pos");
+                TIME_ABL(31, "... and no v_readlane");
+            }
         }
-        printf("chol16_mfma: %.3f us per call (one wave, dependent calls, tile and results through LDS)\n", ms * 1e3 / 2000);
     }
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0); hipLaunchKernelGGL(k_mfma_chain, dim3(1), dim3(64), 0, 0, dout, 100000); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
     printf("dependent mfma_f64_16x16x4: %.1f ns each\n", ms * 1e6 / 100000);
+    {
+        long long* dcyc; hipMalloc(&dcyc, 8);
+        const char* names[9] = {"v_fma_f64", "v_rcp_f64", "rcp_pos", "rsqrt_pos", "v_readlane pair + v_fma_f64", "v_mfma_f64_16x16x4 (acc -> A operand -> acc)",
+                                "v_mfma_f64 -> v_fma_f64 -> v_mfma_f64", "DPP row broadcast pair + v_fma_f64", "ds_bpermute pair + v_mul_f64"};
+#define LAT(W) do { hipLaunchKernelGGL(k_lat<W>, dim3(1), dim3(64), 0, 0, dout, dcyc, 100000); hipEventRecord(e0); hipLaunchKernelGGL(k_lat<W>, dim3(1), dim3(64), 0, 0, dout, dcyc, 100000); hipEventRecord(e1); hipEventSynchronize(e1); \
+            hipEventElapsedTime(&ms, e0, e1); long long c; hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost); \
+            printf("dependent %-48s %7.2f ns each, %7.1f s_memtime ticks each\n", names[W], ms * 1e6 / 400000.0, (double)c / 400000.0); } while (0)
+        LAT(0); LAT(1); LAT(2); LAT(3); LAT(4); LAT(5); LAT(6); LAT(7); LAT(8);
+    }
 
     const int nt = 7, n = nt * 16, nmax = 4096;
     std::vector<double> h((size_t)n * n);
