@@ -1077,6 +1077,104 @@ __device__ __forceinline__ double chol16_mfma(const double* __restrict__ tile /*
     return lg;
 }
 
+// The same blocked atom in square-root-free form (what the measurements of tools/chol_latency.hip asked for: the first version spent
+// its time ISSUING the 4 x 4 work that every lane repeats - 16 rsqrt_pos of 11 instructions each, nested selects, an ocml log - not
+// waiting for its chain).  S = U D U^T with unit-lower U:
+//      Z   = U_pp^-1 S[panel rows, :]                   one MFMA (A = the 4 x 4 unit-lower inverse, zero-padded)
+//      S  -= (D_p^-1 Z)^T Z                             one MFMA; D_p^-1 Z = the multipliers U[:, panel]^T, a per-lane scaling by 1 / d_q
+//      N[panel rows] = U_pp^-1 N[panel rows];  N[below] -= U[below, panel] N[panel rows]        (N: the unit-lower inverse)
+// and only at the end L[r][4p + q] = Z_p[q][r] / sqrt(d_{4p+q}),  L^-1[4p + q][c] = N[4p + q][c] / sqrt(d_{4p+q}): FOUR rsqrt per
+// lane in all (its own pivots).  The log-determinant comes from the product of the pivots (exponents kept apart): one logarithm
+// of one uniform number, no reduction.
+__device__ __forceinline__ double log_pos_uniform(double x) {           // log(x), x > 0 normal: frexp + atanh series; ~1 ulp of the result
+    int e;
+    double m = __builtin_frexp(x, &e);                                   // m in [0.5, 1)
+    if (m < 0.70710678118654752) { m += m; --e; }                       // m in [sqrt(1/2), sqrt(2))
+    const double t = (m - 1.0) * rcp_pos(m + 1.0), t2 = t * t;         // |t| <= 0.1716
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, t2, 1.0 / 19.0); p = __builtin_fma(p, t2, 1.0 / 17.0); p = __builtin_fma(p, t2, 1.0 / 15.0);
+    p = __builtin_fma(p, t2, 1.0 / 13.0); p = __builtin_fma(p, t2, 1.0 / 11.0); p = __builtin_fma(p, t2, 1.0 / 9.0);
+    p = __builtin_fma(p, t2, 1.0 / 7.0); p = __builtin_fma(p, t2, 1.0 / 5.0); p = __builtin_fma(p, t2, 1.0 / 3.0);
+    p = __builtin_fma(p, t2, 1.0);
+    return __builtin_fma((double)e, 0.69314718055994530942, 2.0 * t * p);
+}
+template <int ABL = 0>
+__device__ __forceinline__ double chol16_ldl(const double* __restrict__ tile, double* __restrict__ Lout, double* __restrict__ Iout,
+                                             int lane, bool& bad) {
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 15, q = lane >> 4;
+    d4 s, n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * i + q;
+        s[i] = row >= r ? tile[row * 16 + r] : tile[r * 16 + row];
+        n[i] = row == r ? 1.0 : 0.0;
+    }
+    const d4 zero = {0, 0, 0, 0};
+    double lcol[4], dq[4];
+    double prod = 1.0;
+    int pexp = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        double b[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) b[a][c] = readlane_f64(s[p], (4 * p + c) + 16 * a);
+        double d0 = b[0][0];
+        const double i0 = rcp_pos(d0);
+        const double u10 = b[1][0] * i0, u20 = b[2][0] * i0, u30 = b[3][0] * i0;
+        double d1 = __builtin_fma(-u10, b[1][0], b[1][1]);
+        const double i1 = rcp_pos(d1);
+        const double c21 = __builtin_fma(-u20, b[1][0], b[2][1]), c31 = __builtin_fma(-u30, b[1][0], b[3][1]);
+        const double u21 = c21 * i1, u31 = c31 * i1;
+        double d2 = __builtin_fma(-u21, c21, __builtin_fma(-u20, b[2][0], b[2][2]));
+        const double i2 = rcp_pos(d2);
+        const double c32 = __builtin_fma(-u31, c21, __builtin_fma(-u30, b[2][0], b[3][2]));
+        const double u32 = c32 * i2;
+        double d3 = __builtin_fma(-u32, c32, __builtin_fma(-u31, c31, __builtin_fma(-u30, b[3][0], b[3][3])));
+        const double i3 = rcp_pos(d3);
+        // not positive definite (or NaN): flagged once per panel off the chain; the numbers that follow are garbage either way
+        if (!(fmin(fmin(d0, d1), fmin(d2, d3)) > 0.0)) bad = true;
+        // U_pp^-1 (unit lower), this lane's element of the zero-padded A operand: V[r][q], q <= r < 4
+        const double v20 = __builtin_fma(u21, u10, -u20), v31 = __builtin_fma(u32, u21, -u31);
+        const double v30 = -__builtin_fma(u32, v20, __builtin_fma(-u31, u10, u30));
+        const double vq0 = (r == 1) ? -u10 : (r == 2) ? v20 : v30;           // column q = 0, rows 1 .. 3
+        const double vq1 = (r == 2) ? -u21 : v31;                             // column q = 1, rows 2, 3
+        const double vlow = (q == 0) ? vq0 : (q == 1) ? vq1 : -u32;          // strictly lower part
+        const double va = (r < 4) ? ((q == r) ? 1.0 : (q < r ? vlow : 0.0)) : 0.0;
+        const double iq = (q == 0) ? i0 : (q == 1) ? i1 : (q == 2) ? i2 : i3;
+        dq[p] = (q == 0) ? d0 : (q == 1) ? d1 : (q == 2) ? d2 : d3;
+        // Z = U_pp^-1 S[panel rows, :]; the columns left of the panel are finished
+        const d4 zz = mfma16(va, s[p], zero);
+        const double z = (r >= 4 * p) ? zz[0] : 0.0;
+        const double w = z * iq;                             // U[r][4p + q]
+        lcol[p] = (r >= 4 * p + q) ? z : 0.0;
+        if (p < 3) s = mfma16(-w, z, s);
+        if (!(ABL & 1)) {
+            const d4 np = mfma16(va, n[p], zero);
+            n[p] = np[0];
+            if (p < 3) {
+                const double wb = (r >= 4 * p + 4) ? w : 0.0;
+                n = mfma16(-wb, np[0], n);
+            }
+        }
+        // product of the pivots, exponent kept apart (sixteen pivots of 1e-20 would underflow a plain product)
+        prod *= (d0 * d1) * (d2 * d3);
+        int e2;
+        prod = __builtin_frexp(prod, &e2);
+        pexp += e2;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const double rs = rsqrt_pos(dq[p]);
+        Lout[r * 16 + 4 * p + q] = lcol[p] * rs;
+        Iout[(4 * p + q) * 16 + r] = (4 * p + q >= r) ? n[p] * rs : 0.0;
+    }
+    if (ABL & 8) return prod;
+    return 0.5 * __builtin_fma((double)pexp, 0.69314718055994530942, log_pos_uniform(prod));
+}
+
 // ------------------------------------------------------------------------------------------------
 //  blocked partial Cholesky of a tall panel (one workgroup per problem)
 // ------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void k_c16(double* out, int iters) {
 }
 
 // the blocked atom (chol16_mfma): same dependent-call timing, and a correctness dump of L and L^-1 for one tile
-template <int ABL>
+template <int ABL, int VER = 0>
 __global__ __launch_bounds__(256) void k_c16m(double* out, int iters, const double* tile_in, double* Lres, double* Ires) {
     __shared__ __attribute__((aligned(16))) double st[256], sl[256], si[256];
     const int lane = threadIdx.x & 63;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_c16m(double* out, int iters, const doub
     double acc = 0;
     bool bad = false;
     for (int it = 0; it < iters; ++it) {
-        const double lg = chol16_mfma<ABL>(st, sl, si, lane, bad);
+        const double lg = VER ? chol16_ldl<ABL>(st, sl, si, lane, bad) : chol16_mfma<ABL>(st, sl, si, lane, bad);
         lds_wave_sync();
         acc += lg + si[3 * 16 + 1] + sl[2 * 16 + 1];
         if (lane == 0) st[15 * 16 + 15] += 1e-30 * acc;      // keep the calls dependent
@@ -110,6 +110,14 @@ int main() {
             for (int i = 0; i < 16; ++i) lgh += log(Lh[i * 16 + i]);
             for (int e = 0; e < 256; ++e) { eL = fmax(eL, fabs(Lg[e] - Lh[e]) / (fabs(Lh[e]) + 1e-300 + (Lh[e] == 0))); eI = fmax(eI, fabs(Ig[e] - Ih[e]) / (fabs(Ih[e]) + (Ih[e] == 0))); }
             printf("chol16_mfma tile %d: max rel err L %.2e, L^-1 %.2e; sum log diag host %.15g\n", which, eL, eI, lgh);
+            {
+                hipLaunchKernelGGL((k_c16m<0, 1>), dim3(1), dim3(64), 0, 0, dout, 1, dT, dL, dI);
+                hipMemcpy(Lg, dL, 2048, hipMemcpyDeviceToHost); hipMemcpy(Ig, dI, 2048, hipMemcpyDeviceToHost); hipMemcpy(&o0, dout, 8, hipMemcpyDeviceToHost);
+                eL = eI = 0;
+                for (int e = 0; e < 256; ++e) { eL = fmax(eL, fabs(Lg[e] - Lh[e]) / (fabs(Lh[e]) + 1e-300 + (Lh[e] == 0))); eI = fmax(eI, fabs(Ig[e] - Ih[e]) / (fabs(Ih[e]) + (Ih[e] == 0))); }
+                // out[0] = lg + si[3*16+1] + sl[2*16+1] of the one call
+                printf("chol16_ldl  tile %d: max rel err L %.2e, L^-1 %.2e; sum log diag device %.15g (host %.15g)\n", which, eL, eI, o0 - Ig[3 * 16 + 1] - Lg[2 * 16 + 1], lgh);
+            }
             if (which == 0) {
 #define TIME_ABL(A, label) do { for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL(k_c16m<A>, dim3(1), dim3(64), 0, 0, dout, 2000, dT, dL, dI); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } \
                 printf("chol16_mfma<%2d> %-52s %.3f us per call\n", A, label, ms * 1e3 / 2000); } while (0)
@@ -120,6 +128,11 @@ int main() {
                 TIME_ABL(11, "... and bare v_rcp_f64 instead of rcp_pos");
                 TIME_ABL(15, "... and bare v_rsq_f64 instead of rsqrt_pos");
                 TIME_ABL(31, "... and no v_readlane");
+#define TIME_LDL(A, label) do { for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL((k_c16m<A, 1>), dim3(1), dim3(64), 0, 0, dout, 2000, dT, dL, dI); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } \
+                printf("chol16_ldl <%2d> %-52s %.3f us per call\n", A, label, ms * 1e3 / 2000); } while (0)
+                TIME_LDL(0, "(full)");
+                TIME_LDL(1, "without the inverse's MFMAs");
+                TIME_LDL(9, "without inverse and log");
             }
         }
     }

@@ -14,7 +14,12 @@ python3 bench.py --likelihood-only --no-cpu-baseline --steps 20 --warmup 3 > "$P
 python3 bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline > "$P/${TAG}_bench_c5.json" 2> "$P/c5.err"
 python3 bench.py --config c5 --likelihood-only --steps 5 --warmup 2 --no-cpu-baseline > "$P/${TAG}_bench_c5_likelihood_only.json" 2> "$P/c5l.err"
 python3 tools/shard_timing.py 1 2 4 8 > "$P/${TAG}_shard_emulation_2_4_8.txt" 2>&1
-python3 tools/e2e_breakdown.py > "$P/${TAG}_e2e_breakdown.txt" 2>&1
+python3 tools/shard_timing.py --config c5 1 2 4 8 > "$P/${TAG}_c5_shard_emulation_2_4_8.txt" 2>&1
+python3 tools/shard_timing.py --config c5 --likelihood-only 1 8 > "$P/${TAG}_c5_shard_emulation_likelihood_only_1_8.txt" 2>&1
+MRA_TRACE_PLAN=1 MRA_TRACE_REPLAY=1 python3 tools/e2e_breakdown.py > "$P/${TAG}_e2e_breakdown.txt" 2>&1
+# the N > 1 paths, rehearsed on this one GPU (every rank on device 0, the front exchange through gloo): bench.py starts its own ranks
+MRA_BENCH_SINGLE_DEVICE=1 python3 bench.py --gpus 2 --exchange gloo --steps 10 --warmup 3 --no-cpu-baseline > "$P/${TAG}_bench_2ranks_one_gpu_gloo_rehearsal.json" 2> "$P/g2.err"
+MRA_BENCH_SINGLE_DEVICE=1 python3 bench.py --config c5 --gpus 4 --exchange gloo --mle --steps 3 --warmup 1 --no-cpu-baseline > "$P/${TAG}_bench_c5_4ranks_one_gpu_gloo_rehearsal_mle.json" 2> "$P/c5g4.err"
 bash tools/trace_kernels.sh 1gpu -- python3 tools/one_pass.py 1 > "$P/${TAG}_trace_one_pass_1gpu.txt" 2>&1
 bash tools/trace_kernels.sh 8way -- python3 tools/one_pass.py 8 > "$P/${TAG}_trace_one_pass_8way_shard_rank0.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${TAG}_c5" -- python3 bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > "$P/c5_kt.log" 2>&1
