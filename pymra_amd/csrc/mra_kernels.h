@@ -1098,16 +1098,18 @@ __device__ __forceinline__ double log_pos_uniform(double x) {           // log(x
     p = __builtin_fma(p, t2, 1.0);
     return __builtin_fma((double)e, 0.69314718055994530942, 2.0 * t * p);
 }
+// tile / Lout / Iout: LDS, rows of ldt / ldl / ldi doubles (Lout may be the tile itself: every lane has read its share before
+// anybody writes); gL / gI (optional, global memory): the same two results once more, rows of gldl / 16 doubles
 template <int ABL = 0>
-__device__ __forceinline__ double chol16_ldl(const double* __restrict__ tile, double* __restrict__ Lout, double* __restrict__ Iout,
-                                             int lane, bool& bad) {
+__device__ __forceinline__ double chol16_ldl(const double* tile, int ldt, double* Lout, int ldl, double* Iout, int ldi,
+                                             int lane, bool& bad, double* __restrict__ gL = nullptr, long gldl = 0, double* __restrict__ gI = nullptr) {
     asm volatile("" : "+v"(lane));
     const int r = lane & 15, q = lane >> 4;
     d4 s, n;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 4 * i + q;
-        s[i] = row >= r ? tile[row * 16 + r] : tile[r * 16 + row];
+        s[i] = row >= r ? tile[row * ldt + r] : tile[r * ldt + row];
         n[i] = row == r ? 1.0 : 0.0;
     }
     const d4 zero = {0, 0, 0, 0};
@@ -1168,8 +1170,11 @@ __device__ __forceinline__ double chol16_ldl(const double* __restrict__ tile, do
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const double rs = rsqrt_pos(dq[p]);
-        Lout[r * 16 + 4 * p + q] = lcol[p] * rs;
-        Iout[(4 * p + q) * 16 + r] = (4 * p + q >= r) ? n[p] * rs : 0.0;
+        const double lv = lcol[p] * rs, iv = (4 * p + q >= r) ? n[p] * rs : 0.0;
+        Lout[r * ldl + 4 * p + q] = lv;
+        Iout[(4 * p + q) * ldi + r] = iv;
+        if (gL) gst(gL + (long)r * gldl + 4 * p + q, lv);
+        if (gI) gst(gI + (4 * p + q) * 16 + r, iv);
     }
     if (ABL & 8) return prod;
     return 0.5 * __builtin_fma((double)pexp, 0.69314718055994530942, log_pos_uniform(prod));
@@ -1221,11 +1226,12 @@ __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restri
         __syncthreads();
         // ---- phase 2: factorise + invert the diagonal block (wave 0)
         if (wave == 0) {
+            bool bad = false;
+#ifdef MRA_ATOM_OLD
             double a[16], m[16];
             const int rl = lane & 15;
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= rl) ? sd[rl][k] : 0.0;
-            bool bad = false;
             double ls = chol16_inv(a, m, rl, bad, &sd[0][0]);
             logacc += ls;
             if (lane < 16) {
@@ -1237,8 +1243,11 @@ __global__ __launch_bounds__(256, 2) void k_panel_chol(const PanelProb* __restri
                 for (int k = 0; k < 16; ++k) sinv[lane][k] = m[k];
 #pragma unroll
                 for (int k = 0; k < 16; k += 2) gst2(ip + lane * 16 + k, d2{m[k], m[k + 1]});
-                if (bad && lane == 0) atomicMax(err, pb.node + 1);
             }
+#else
+            logacc += chol16_ldl(&sd[0][0], 17, &sd[0][0], 17, &sinv[0][0], 17, lane, bad, pb.P + (long)(jb * 16) * pb.ld + jb * 16, pb.ld, pb.invd + (long)jb * 256);
+#endif
+            if (bad && lane == 0) atomicMax(err, pb.node + 1);
         }
         __syncthreads();
         // ---- phase 3: rows below: X^T = L_jj^{-1} T^T
@@ -1296,6 +1305,7 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
             *(d4*)(sd + r * 16 + 4 * q) = acc;
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef MRA_ATOM_OLD
         {
             double a[16], m[16];
 #pragma unroll
@@ -1310,6 +1320,11 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
                 for (int k = 0; k < 16; k += 2) { *(d2*)(si + lane * 16 + k) = d2{m[k], m[k + 1]}; gst2(ip2 + lane * 16 + k, d2{m[k], m[k + 1]}); }
             }
         }
+#else
+        // factor + inverse on the matrix cores (chol16_ldl): L over the tile in LDS and to the matrix in global memory, the inverse
+        // into si and to invd
+        logacc += chol16_ldl(sd, 16, sd, 16, si, 16, lane, bad, P + (long)(jb * 16) * ld + jb * 16, ld, invd + (long)jb * 256);
+#endif
         __builtin_amdgcn_wave_barrier();
         const d4 ia = *(const d4*)(si + prow * 16 + 4 * q);
         // ---- rows below
@@ -1337,7 +1352,7 @@ __device__ __forceinline__ double chol_wave_body(double* __restrict__ P, long ld
 }
 
 template <int NTMAX>
-__global__ __launch_bounds__(256, 3) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
+__global__ __launch_bounds__(256, 4) void k_chol_wave(const PanelProb* __restrict__ probs, int nprob,
                                                     double* __restrict__ dnode, int* __restrict__ err) {
     __shared__ __attribute__((aligned(16))) double sdiag[4][16 * 16 + 32];     // 272 used: tile + exchange column
     __shared__ __attribute__((aligned(16))) double sinv[4][16 * 16];
@@ -1408,6 +1423,7 @@ __global__ __launch_bounds__(NW * 64, NT <= 8 ? 3 : 2) void k_chol_tiles(const P
         bool bad = false;
         // factorise + invert diagonal tile jd: factor to global memory, inverse into finv and to global memory
         auto factor = [&](int jd) {
+#ifdef MRA_ATOM_OLD
             double a[16], m[16];
             const double* dt = sdiag + jd * 256;
 #pragma unroll
@@ -1423,6 +1439,10 @@ __global__ __launch_bounds__(NW * 64, NT <= 8 ? 3 : 2) void k_chol_tiles(const P
                     gst2(ip2 + lane * 16 + k, d2{m[k], m[k + 1]});
                 }
             }
+#else
+            double* dt = sdiag + jd * 256;
+            logacc += chol16_ldl(dt, 16, dt, 16, finv, 16, lane, bad, pb.P + (long)(jd * 16) * pb.ld + jd * 16, pb.ld, pb.invd + (long)jd * 256);
+#endif
         };
         factor(0);
         __syncthreads();
@@ -2477,8 +2497,9 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
                 bool bad = false;
 #pragma unroll
                 for (int jb = 0; jb < 2; ++jb) {
-                    double a[16], mi[16];
                     double* dt = fs + (long)(jb * (jb + 1) / 2 + jb) * FT_SZ;
+#ifdef MRA_ATOM_OLD
+                    double a[16], mi[16];
 #pragma unroll
                     for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
                     chol16_inv(a, mi, r, bad, nullptr);
@@ -2489,6 +2510,9 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
                             *(d2*)(finv + jb * FT_SZ + lane * FT_LD + k) = d2{mi[k], mi[k + 1]};
                         }
                     }
+#else
+                    chol16_ldl<8>(dt, FT_LD, dt, FT_LD, finv + jb * FT_SZ, FT_LD, lane, bad);       // (<8>: the log-determinant is not wanted here)
+#endif
                     if (jb == 0) {
                         lds_wave_sync();
                         const d4 ia = *(const d4*)(finv + prow * FT_LD + 4 * q);
@@ -2527,11 +2551,12 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
                 __syncthreads();
             }
             if (wave == 0) {
-                double a[16], mi[16];
                 double* dt = fs + (long)(jb * (jb + 1) / 2 + jb) * FT_SZ;
+                bool bad = false;
+#ifdef MRA_ATOM_OLD
+                double a[16], mi[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
-                bool bad = false;
                 chol16_inv(a, mi, r, bad, nullptr);
                 if (lane < 16) {
 #pragma unroll
@@ -2539,8 +2564,11 @@ __global__ __launch_bounds__(256, 1) void k_knot_chain(KnotChainArgs ka, KernelP
                         *(d2*)(dt + lane * FT_LD + k) = d2{a[k], a[k + 1]};
                         *(d2*)(finv + jb * FT_SZ + lane * FT_LD + k) = d2{mi[k], mi[k + 1]};
                     }
-                    if (bad && lane == 0) atomicMax(ka.err, ka.node_base[m] + slot + 1);
                 }
+#else
+                chol16_ldl<8>(dt, FT_LD, dt, FT_LD, finv + jb * FT_SZ, FT_LD, lane, bad);
+#endif
+                if (bad && lane == 0) atomicMax(ka.err, ka.node_base[m] + slot + 1);
             }
             __syncthreads();
             {
@@ -3432,11 +3460,12 @@ __global__ __launch_bounds__(512, 1) void k_front(const FrontProb* __restrict__ 
             __syncthreads();
         }
         if (wave == 0) {
-            double a[16], m[16];
             double* dt = lds + (long)tix(jb, jb) * FT_SZ;
+            bool bad = false;
+#ifdef MRA_ATOM_OLD
+            double a[16], m[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
-            bool bad = false;
             logacc += chol16_inv(a, m, r, bad, nullptr);
             if (lane < 16) {
 #pragma unroll
@@ -3445,8 +3474,11 @@ __global__ __launch_bounds__(512, 1) void k_front(const FrontProb* __restrict__ 
                     *(d2*)(inv + jb * FT_SZ + lane * FT_LD + k) = d2{m[k], m[k + 1]};
                     gst2(pp->invd + (long)jb * 256 + lane * 16 + k, d2{m[k], m[k + 1]});
                 }
-                if (bad && lane == 0) atomicMax(err, pp->node + 1);
             }
+#else
+            logacc += chol16_ldl(dt, FT_LD, dt, FT_LD, inv + jb * FT_SZ, FT_LD, lane, bad, nullptr, 0, pp->invd + (long)jb * 256);
+#endif
+            if (bad && lane == 0) atomicMax(err, pp->node + 1);
         }
         __syncthreads();
         {
@@ -3630,11 +3662,12 @@ __global__ __launch_bounds__(512, 1) void k_parent_front(const FrontProb* __rest
             __syncthreads();
         }
         if (wave == nwave - 1) {
-            double a[16], m[16];
             double* dt = pan + (long)tix(jb, jb) * FT_SZ;
+            bool bad = false;
+#ifdef MRA_ATOM_OLD
+            double a[16], m[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (k <= r) ? dt[r * FT_LD + k] : 0.0;
-            bool bad = false;
             logacc += chol16_inv(a, m, r, bad, nullptr);
             if (lane < 16) {
 #pragma unroll
@@ -3643,8 +3676,11 @@ __global__ __launch_bounds__(512, 1) void k_parent_front(const FrontProb* __rest
                     *(d2*)(inv + jb * FT_SZ + lane * FT_LD + k) = d2{m[k], m[k + 1]};
                     gst2(pp->invd + (long)jb * 256 + lane * 16 + k, d2{m[k], m[k + 1]});
                 }
-                if (bad && lane == 0) atomicMax(err, pp->node + 1);
             }
+#else
+            logacc += chol16_ldl(dt, FT_LD, dt, FT_LD, inv + jb * FT_SZ, FT_LD, lane, bad, nullptr, 0, pp->invd + (long)jb * 256);
+#endif
+            if (bad && lane == 0) atomicMax(err, pp->node + 1);
         }
         __syncthreads();
         {

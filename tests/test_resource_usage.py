@@ -3,7 +3,7 @@ is part of done").  __graft_entry__.build() compiles every translation unit with
 the remarks of that very build next to the library (pymra_amd/libmra_hip.resource_usage.txt); this test parses them - no
 second compile - and fails when a kernel that a C3 / C5 pass launches (one GPU or a shard) uses scratch memory, or when any
 other kernel starts to.  Exceptions among the production kernels are PINNED (exact byte counts: growth fails the test, and so
-does an improvement that forgets to delete the entry): k_parent_front<12>.
+does an improvement that forgets to delete the entry); none at present.
 
 ALLOWED lists the known exceptions with their bound and the reason; anything else must report 0 bytes of scratch."""
 import os
@@ -26,11 +26,10 @@ PRODUCTION = [
     # shards (at most two leaves per CU) and config 5
     r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
     r"k_predict_cascade<2, 6, 4, true, 3>", r"k_predict_cascade<2, 6, 4, false, 3>", r"k_predict_cascade<4, 4, 8, false, 1>",
+    r"k_parent_front<12>",
 ]
 # production kernels with a known, pinned amount of scratch: (pattern, exact bytes per lane)
-PINNED = [
-    (r"k_parent_front<12>", 36),                          # around chol16_inv, once per workgroup, outside the K loop
-]
+PINNED = []      # (round 4: k_parent_front<12> lost its 36 B with the blocked factorisation atom, the predictive cascades theirs with half staging)
 # (pattern, max scratch bytes per lane, reason)
 ALLOWED = [
     # Kanter taper: ocml sin/cos (Payne-Hanek range reduction keeps a private table on the stack); not a spill
@@ -43,9 +42,6 @@ ALLOWED = [
     # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
     # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
     (r"k_predict_cascade<2, 8, 8, (true|false), 1>", 72, "eight row tiles per workgroup at 7-8 levels: not launched (cascade_wpw = 4)"),
-    # the diagonal-block routine (chol16_inv, ~100 registers) runs beside 96 accumulator registers; the spills sit around it,
-    # once per workgroup, outside the K loop
-    (r"k_parent_front<12>", 40, "around chol16_inv, outside the K loop"),
     # instantiations no benchmark configuration launches (CWT = 4 cascades of shallow wide trees, 8-level CWT = 2 with update)
     (r"k_predict_cascade<4, 4, \d, (true|false), \d>", 600, "not launched by C1-C5; superseded by the two-group cascade for r0 = 64"),
     (r"k_predict_cascade<2, 8, 4, true, 2>", 24, "7-8 level CWT = 2 trees only"),

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_c16m(double* out, int iters, const doub
     double acc = 0;
     bool bad = false;
     for (int it = 0; it < iters; ++it) {
-        const double lg = VER ? chol16_ldl<ABL>(st, sl, si, lane, bad) : chol16_mfma<ABL>(st, sl, si, lane, bad);
+        const double lg = VER ? chol16_ldl<ABL>(st, 16, sl, 16, si, 16, lane, bad) : chol16_mfma<ABL>(st, sl, si, lane, bad);
         lds_wave_sync();
         acc += lg + si[3 * 16 + 1] + sl[2 * 16 + 1];
         if (lane == 0) st[15 * 16 + 15] += 1e-30 * acc;      // keep the calls dependent
