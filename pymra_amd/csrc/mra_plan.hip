@@ -1606,7 +1606,11 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             KTimer kt(pl, KF_LEAF_CHOL, pred ? pl->fl_leaf_chol : pl->fl_leaf_chol_lik);
             const int ntl = pl->leaf_max_nop / 16;
             if (ntl <= 12) {
-                if (ntl <= 10 && (pl->use_chol_lds == 2 || (pl->use_chol_lds == 1 && nl <= (size_t)(2 * pl->n_cu)))) {
+                // (round 4, with the blocked factorisation atom: one workgroup per matrix is at least as fast as one wave per matrix at
+                //  every shard size - 5.507 / 3.00 / 1.601 / 0.922 ms against 5.528 / 3.00 / 1.621 / 0.959 for 1 / 2 / 4 / 8-way C3 -
+                //  so option 11 = 1 (the default) takes it for matrices of five tiles and more at any count; small matrices - config 5:
+                //  65536 of at most three tiles - stay on one wave each unless a CU sees at most two of them; 0 forces k_chol_wave)
+                if (ntl <= 10 && (pl->use_chol_lds == 2 || (pl->use_chol_lds == 1 && (ntl >= 5 || nl <= (size_t)(2 * pl->n_cu))))) {
                     // one workgroup per matrix, tiles in registers, next diagonal block factorised beside the trailing update
                     const size_t ns = pl->n_chol_small;
                     if (ns == nl || nl > (size_t)(2 * pl->n_cu)) {
