@@ -34,7 +34,18 @@ def test_dominant_kernel_duration_agrees_with_the_rocprof_trace():
     dom = bench["roofline"]["kernel"]
     assert dom in dur
     a, b = dur[dom]["avg_us"] * 1e-3, bench["roofline"]["avg_launch_ms"]
-    assert abs(a - b) <= 0.05 * b, (a, b)          # hipEvents inside bench.py vs rocprofv3 of the same command
+    # rocprofv3's trace against bench.py's own hipEvents: the SAME process where its line was kept (the bench line printed under
+    # the profiler, round 4 on), to 5 %; the committed un-profiled line is another run of the same command on the same box (clocks
+    # and the tracer's presence differ by a few per cent): 8 %
+    same = os.path.join(ROOT, "profiles", tag + "_bench_under_rocprofv3_kernel_trace.json")
+    if os.path.exists(same):
+        bs = json.load(open(same))
+        assert bs["roofline"]["kernel"] == dom
+        b_same = bs["roofline"]["avg_launch_ms"]
+        assert abs(a - b_same) <= 0.05 * b_same, (a, b_same)
+        assert abs(a - b) <= 0.08 * b, (a, b)
+    else:
+        assert abs(a - b) <= 0.05 * b, (a, b)
     tr = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic_by_kernel_family.json")))
     assert abs(tr[dom]["hbm_bytes_per_launch"] - bench["roofline"]["traffic"]) <= 1e-6 * bench["roofline"]["traffic"]
     raw = bench["roofline"]["traffic_raw_counters"]

@@ -24,5 +24,7 @@ bash tools/trace_kernels.sh 1gpu -- python3 tools/one_pass.py 1 > "$P/${TAG}_tra
 bash tools/trace_kernels.sh 8way -- python3 tools/one_pass.py 8 > "$P/${TAG}_trace_one_pass_8way_shard_rank0.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_${TAG}_c5" -- python3 bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > "$P/c5_kt.log" 2>&1
 cp $(ls -t gpurun_out/prof_${TAG}_c5/*/*_kernel_stats.csv | head -1) "$P/${TAG}_c5_rocprofv3_kernel_stats.csv"
+# (gloo prints its rank chatter on stdout: keep the JSON line)
+for f in "$P/${TAG}_bench_2ranks_one_gpu_gloo_rehearsal.json" "$P/${TAG}_bench_c5_4ranks_one_gpu_gloo_rehearsal_mle.json"; do grep '^{"metric"' "$f" > "$f.tmp" && mv "$f.tmp" "$f"; done
 rm -f "$P"/*.err "$P"/*.log
 ls -la "$P"

@@ -2,7 +2,9 @@
 import collections, csv, glob, json, os, shutil, sys
 
 def family(name, grid, maxgrid):
-    """rocprof kernel name (+ grid) -> bench.py kernel family name (mra_plan.hip kfam_name[0], the fused path)"""
+    """rocprof kernel name (+ grid) -> bench.py kernel family name (mra_plan.hip kfam_name[0], the fused path); None for the
+    runtime's own fill / copy kernels (hipMemset / hipMemcpy of the set-up: not part of a pass)"""
+    if name.startswith("__amd_rocclr"): return None
     if name.startswith("void k_prior_cascade"):
         return "k_prior_cascade row pass (W of all levels)" if grid == maxgrid.get("cascade") else KNOT
     if name.startswith("void k_knot_chain"): return KNOT
@@ -13,7 +15,8 @@ def family(name, grid, maxgrid):
     if name.startswith("void k_parent_front"): return "k_parent_front (children's Ut -> parent front -> Lt, Zt, Schur)"
     if name.startswith("void k_front"): return "k_front (assembly + partial Cholesky + Schur per level)"
     if name.startswith("void k_gemm_nt<1"): return "k_gemm_nt<SUB> front Schur complement (fronts too large for LDS)"
-    if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave"): return "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)"
+    if name.startswith("void k_trsm_rows2") or name.startswith("void k_chol_wave") or name.startswith("void k_chol_tiles"):
+        return "k_chol_wave + k_trsm_rows2 leaf factor and solves (Lc, Ut, Tt)"
     return SMALL
 
 KNOT = "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesky)"
@@ -48,7 +51,8 @@ def main():
             pass
         fam_d = collections.defaultdict(list)
         for r in rows:
-            fam_d[family(r["Kernel_Name"], gs(r), mg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            fam = family(r["Kernel_Name"], gs(r), mg)
+            if fam is not None: fam_d[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         json.dump({f: {"launches": len(v), "avg_us": sum(v) / len(v), "total_us": sum(v)} for f, v in sorted(fam_d.items())},
                   open(os.path.join(dst, tag + "_kernel_family_durations.json"), "w"), indent=1)
 
@@ -67,6 +71,7 @@ def main():
         disp = collections.defaultdict(set)
         for r in rows:
             fam = family(r["Kernel_Name"], int(r["Grid_Size"]), mg)
+            if fam is None: continue
             acc[fam].append(float(r["Counter_Value"]))
             disp[fam].add(r["Dispatch_Id"])
         for fam, v in acc.items():
