@@ -649,7 +649,13 @@ static void build_static(mra_plan* pl) {
 // built beside the knot draws (mra_plan_create_replay_2d) gets their contents here, once the draws are done.
 static void fill_knot_arrays(mra_plan* pl) {
     if ((long)pl->knot_rows.size() != pl->knot_ptr.back()) throw MraError(MRA_ERR_INVALID, "knot_rows does not match knot_ptr");
-    if (!pl->knot_rows.empty()) pl->knots_dev.fill(pl->knot_rows);
+    // (the device only ever looks at the knot rows of NON-leaf nodes - the kInv gather of the level-by-level prior; the leaves'
+    //  entries, nine tenths of the 8 MB at 1024^2, stay on the host)
+    {
+        long kmax = 0;
+        for (int i = 0; i < pl->n_nodes; ++i) if (!pl->leaf[i]) kmax = std::max(kmax, pl->knot_ptr[i + 1]);
+        if (kmax > 0) HIP_TRY(mraMemcpy(pl->knots_dev.p, pl->knot_rows.data(), (size_t)kmax * sizeof(long), hipMemcpyHostToDevice));
+    }
     std::vector<int> kidx(pl->knot_idx.n, -1);
     for (int i = 0; i < pl->n_nodes; ++i) {
         if (pl->leaf[i]) continue;
