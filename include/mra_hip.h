@@ -160,6 +160,9 @@ int mra_release_cached_memory(void);
 int mra_plan_set_locs_rows(mra_plan *plan, const double *locs, const int64_t *src);
 int mra_plan_set_obs_rows(mra_plan *plan, const double *y, const int64_t *src, const int64_t *perm, double R);
 int mra_get_predict_rows(mra_plan *plan, const int64_t *perm, const uint8_t *in_leaf, int64_t N, double *mean, double *var);
+/* The same with sd = sqrt(var) written beside it (MRATree.predict returns np.sqrt(root.var), pyMRA/MRATree.py:93); sd may be NULL. */
+int mra_get_predict_rows_sd(mra_plan *plan, const int64_t *perm, const uint8_t *in_leaf, int64_t N, double *mean, double *var,
+                            double *sd);
 
 /* Per-phase device milliseconds of the last mra_run (hipEvent deltas on the plan's stream):
  * out[0]=prior, [1]=leaf, [2]=fronts, [3]=predict, [4]=total; returns how many were written.

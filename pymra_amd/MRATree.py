@@ -135,9 +135,9 @@ class MRATree(object):
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()
         if want_predict:
-            mean, var = self.plan.predict()
+            mean, var, self._sd = self.plan.predict(with_sd=True)      # (sd beside var: predict() returns it, as the reference's np.sqrt(root.var))
         else:
-            mean, var = None, None
+            mean, var, self._sd = None, None, None
         self.root = RootView(d, u, mean, var, N, self.topology, np.asarray(locs, dtype=np.float64), spec)
         self._node_blocks = {}
 
@@ -154,7 +154,7 @@ class MRATree(object):
         if self.root.mean is None:
             raise RuntimeError("constructed with want_predict=False")
         xP = self.root.mean
-        sdP = np.sqrt(self.root.var)
+        sdP = self._sd if self._sd is not None else np.sqrt(self.root.var)
         return xP, sdP
 
     # ---- diagnostics surface (pyMRA/MRATree.py:101-132, 445-511); host-side de-whitening, see pymra_amd.diagnostics
@@ -192,6 +192,6 @@ class MRATree(object):
         self.plan.set_kernel(spec.kind, spec.l, spec.sig, spec.scale, spec.circular)
         self.plan.run(likelihood=True, predict=want_predict)
         d, u = self.plan.likelihood()
-        mean, var = self.plan.predict() if want_predict else (None, None)
+        mean, var, self._sd = self.plan.predict(with_sd=True) if want_predict else (None, None, None)
         self.root = RootView(d, u, mean, var, len(self.locs), self.topology, np.asarray(self.locs, dtype=np.float64), spec)
         return self.getLikelihood()

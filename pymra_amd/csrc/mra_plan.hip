@@ -10,6 +10,7 @@
 // DESIGN.md section 3 derives the factorised form; oracle/mra_levelwise.py is its NumPy twin.
 #include "mra_plan_types.h"
 #include "mra_topology.h"
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -175,6 +176,13 @@ static void drop_arena(mra_plan* pl) {
     if (g_dry && pl->arena.host) { free(pl->arena.host); pl->arena.host = nullptr; }
 }
 
+bool mra_big_lds_once(int device, const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    return done.insert({device, fn}).second;
+}
+
 static void derive_kernel_params(KernelParams& kp) {
     kp.mode = 0; kp.a1 = 0.0; kp.a2 = 0.0; kp.amp = kp.scale * kp.sig;
     kp.inv_2l2 = 1.0 / (2.0 * (kp.l * kp.l));
@@ -297,14 +305,7 @@ static void build_static(mra_plan* pl) {
     pl->leaf_slot.assign(pl->n_nodes, -1);
     for (int i = 0; i < pl->n_nodes; ++i)
         if (pl->leaf[i]) { pl->leaf_slot[i] = (int)pl->leaf_nodes.size(); pl->leaf_nodes.push_back(i); }
-    {
-        std::vector<int> rl(pl->P, -1);
-        for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
-            const int i = pl->leaf_nodes[t];
-            for (long p = pl->row0[i]; p < pl->row1[i]; ++p) rl[p] = (int)t;
-        }
-        pl->row_leaf.upload(rl);
-    }
+    // (row_leaf - padded row -> leaf, 4 bytes per row - is read by two kernels of the general path only: built on first use, ensure_row_leaf)
     // Gt of the leaves
     pl->leaf_goff.assign(pl->leaf_nodes.size() + 1, 0);
     for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
@@ -339,8 +340,6 @@ static void build_static(mra_plan* pl) {
         std::vector<Trsm2Prob> t2pr(nn), t2po(nn);
         std::vector<AsmProb> as(nn);
         std::vector<FrontProb> fr(nn);
-        std::vector<int> tnode;
-        std::vector<long> trow;
         const int Kanc = pl->Ka - lv.a0;
         for (size_t s = 0; s < nn; ++s) {
             const int i = lv.nodes[s];
@@ -368,7 +367,6 @@ static void build_static(mra_plan* pl) {
             t2pr[s] = Trsm2Prob{Lp, lv.invP.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.cw, pl->ldw, lv.cwt, (int)(nr / 16), 0, -1.0, nullptr, nullptr, 0, 0};
             t2po[s] = Trsm2Prob{F, lv.invF.p + s * (size_t)lv.cwt * 256, pl->W.p + r0 * pl->ldw + lv.c0, pl->var.p + r0, lv.ldf, pl->ldw, lv.cwt, (int)(nr / 16), 0, 1.0, nullptr, nullptr, 0, 0};
             lv.max_tiles = std::max(lv.max_tiles, nr / 16);
-            for (long t = 0; t < nr; t += 16) { tnode.push_back((int)s); trow.push_back(r0 + t); }
             fch[s] = PanelProb{F, lv.invF.p + s * (size_t)lv.cwt * 256, lv.ldf, lv.nf / 16, lv.cwt, i};
             lv.fl_fchol += Work(rkt * rkt * rkt / 3.0 + nat * rkt * rkt, (double)lv.cw * lv.cw * lv.cw / 3.0 + (double)lv.na * lv.cw * lv.cw,
                                 8.0 * (2.5 * lv.nf * (lv.nf + 1) / 2));      // four children's Schur blocks in (lower halves; fewer for ragged trees), the front out
@@ -420,8 +418,7 @@ static void build_static(mra_plan* pl) {
         lv.gPriorChol.upload(pch); lv.gFrontChol.upload(fch); lv.gTrsmPrior.upload(tpr); lv.gTrsmPost.upload(tpo);
         lv.gAsm.upload(as);
         lv.gTrsm2Prior.upload(t2pr); lv.gTrsm2Post.upload(t2po);
-        lv.ntiles = (long)tnode.size();
-        lv.tile_node.upload(tnode); lv.tile_row0.upload(trow);
+        // (tile_node / tile_row0 - one entry per row tile of the level - serve the row solve of blocks wider than 192 only: ensure_tile_lists)
     }
     pl->asmKids.upload(kids);
     pl->hKids = kids;
@@ -1066,6 +1063,29 @@ static void build_leaf(mra_plan* pl, const double* y) {
 // ------------------------------------------------------------------------------------------------
 //  launch helpers
 // ------------------------------------------------------------------------------------------------
+// ---- arrays that only the general (level-by-level) kernels read, built when one of those kernels is about to be launched ------
+static void ensure_row_leaf(mra_plan* pl) {
+    if (pl->row_leaf.p) return;
+    std::vector<int> rl(pl->P, -1);
+    for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
+        const int i = pl->leaf_nodes[t];
+        for (long p = pl->row0[i]; p < pl->row1[i]; ++p) rl[p] = (int)t;
+    }
+    pl->row_leaf.upload(rl);
+}
+static void ensure_tile_lists(mra_plan* pl, int m) {
+    LevelData& lv = pl->lev[m];
+    if (lv.tile_node.p) return;
+    std::vector<int> tnode;
+    std::vector<long> trow;
+    for (size_t s = 0; s < lv.nodes.size(); ++s) {
+        const int i = lv.nodes[s];
+        for (long t = pl->row0[i]; t < pl->row1[i]; t += 16) { tnode.push_back((int)s); trow.push_back(t); }
+    }
+    lv.ntiles = (long)tnode.size();
+    lv.tile_node.upload(tnode); lv.tile_row0.upload(trow);
+}
+
 struct KTimer {
     mra_plan* pl; int fam; hipEvent_t a = nullptr, b = nullptr;
     KTimer(mra_plan* p, int f, const Work& w) : pl(p), fam(f) {
@@ -1426,10 +1446,12 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
             if (!nn) continue;
             {
                 KTimer kt(pl, KF_PRED_TRSM, lv.fl_trsm);
-                if (!launch_trsm2(pl, lv.gTrsm2Post.p, nn, lv.cwt, lv.max_tiles, 32))
-                hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
-                                   lv.gTrsmPost.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw,
-                                   lv.c0, pl->var.p);
+                if (!launch_trsm2(pl, lv.gTrsm2Post.p, nn, lv.cwt, lv.max_tiles, 32)) {
+                    ensure_tile_lists(pl, m);
+                    hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
+                                       lv.gTrsmPost.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw,
+                                       lv.c0, pl->var.p);
+                }
             }
             { KTimer kt(pl, KF_PRED_UPDATE, lv.fl_update); launch_gemm<EPI_SUB>(pl, lv.gUpdate.p, nn, lv.max_rows, lv.na); }
         }
@@ -1565,10 +1587,12 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
         {
             KTimer kt(pl, KF_PRIOR_TRSM, lv.fl_trsm);
-            if (!launch_trsm2(pl, lv.gTrsm2Prior.p, nn, lv.cwt, lv.max_tiles, 32))
-            hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
-                               lv.gTrsmPrior.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw, lv.c0,
-                               (double*)nullptr);
+            if (!launch_trsm2(pl, lv.gTrsm2Prior.p, nn, lv.cwt, lv.max_tiles, 32)) {
+                ensure_tile_lists(pl, m);
+                hipLaunchKernelGGL(k_trsm_rows, dim3((unsigned)((lv.ntiles + 3) / 4)), dim3(256), 0, pl->stream,
+                                   lv.gTrsmPrior.p, lv.tile_node.p, lv.tile_row0.p, lv.ntiles, pl->W.p, (long)pl->ldw, lv.c0,
+                                   (double*)nullptr);
+            }
         }
     }
     phase_mark(pl, 1);
@@ -1676,6 +1700,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             }
             if (!fused && pl->var_accumulated) {
                 KTimer kt(pl, KF_MISC, 0);
+                ensure_row_leaf(pl);
                 hipLaunchKernelGGL(k_leaf_finish_var, dim3((unsigned)((pl->P + 255) / 256)), dim3(256), 0, pl->stream, pl->row_leaf.p, pl->W.p,
                                    (long)pl->ldw, pl->Ka, pl->var.p, pl->P);
             } else if (!fused || pl->leaf_max_nop / 16 > 12) {
@@ -1690,6 +1715,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
                         default: cov0 = kp.scale; break;
                     }
                 }
+                ensure_row_leaf(pl);
                 hipLaunchKernelGGL(k_leaf_moments, dim3((unsigned)((pl->P + 3) / 4)), dim3(256), 0, pl->stream, pl->gLeaf.p,
                                    pl->row_leaf.p, pl->W.p, (long)pl->ldw, pl->Ka, pl->var.p, cov0,
                                    pl->host_cov ? pl->covdiag.p : (const double*)nullptr, pl->P);
@@ -1962,6 +1988,10 @@ int mra_plan_set_obs_rows(mra_plan* pl, const double* y, const int64_t* src, con
 }
 
 int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_leaf, int64_t N, double* mean, double* var) {
+    return mra_get_predict_rows_sd(pl, perm, in_leaf, N, mean, var, nullptr);
+}
+
+int mra_get_predict_rows_sd(mra_plan* pl, const int64_t* perm, const uint8_t* in_leaf, int64_t N, double* mean, double* var, double* sd) {
     if (!pl || !perm || !in_leaf || !mean || !var || N <= 0) return MRA_ERR_INVALID;
     try {
         PlanTrace tr("get_predict_rows");
@@ -1971,12 +2001,24 @@ int mra_get_predict_rows(mra_plan* pl, const int64_t* perm, const uint8_t* in_le
         const int rc = mra_get_predict(pl, st, st + pl->P);
         if (rc != MRA_OK) return rc;
         tr.mark("D2H mean, var");
-        parallel_rows(N, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { mean[i] = 0.0; var[i] = 0.0; } });
-        tr.mark("zero the caller's arrays");
         const double* mp = st; const double* vp = st + pl->P;
-        // every caller row sits in exactly one padded row, so the scatter has no write conflicts between threads
+        // rows that no leaf reports (dropped by a partition, or another rank's) read 0 - written only when there are such rows
+        std::atomic<int64_t> covered{0};
         parallel_rows(pl->P, [&](int64_t a, int64_t b) {
-            for (int64_t p = a; p < b; ++p) if (in_leaf[p]) { const int64_t i = perm[p]; if (i >= 0 && i < N) { mean[i] = mp[p]; var[i] = vp[p]; } }
+            int64_t c = 0;
+            for (int64_t p = a; p < b; ++p) c += (in_leaf[p] && perm[p] >= 0 && perm[p] < N) ? 1 : 0;
+            covered += c;
+        });
+        if (covered.load() != N) {
+            parallel_rows(N, [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) { mean[i] = 0.0; var[i] = 0.0; if (sd) sd[i] = 0.0; } });
+            tr.mark("zero the caller's arrays");
+        }
+        // every caller row sits in at most one padded row, so the scatter has no write conflicts between threads
+        parallel_rows(pl->P, [&](int64_t a, int64_t b) {
+            for (int64_t p = a; p < b; ++p) if (in_leaf[p]) {
+                const int64_t i = perm[p];
+                if (i >= 0 && i < N) { mean[i] = mp[p]; var[i] = vp[p]; if (sd) sd[i] = std::sqrt(vp[p]); }
+            }
         });
         return MRA_OK;
     } catch (const MraError& e) { return fail(pl, e); }

@@ -385,12 +385,14 @@ struct mra_plan {
     bool prepare_only = false;           // mra_plan_prepare: the launch helpers set their attributes and return
 };
 
-// Dynamic LDS above 64 KiB has to be requested per kernel and per DEVICE.  A process-wide "done" flag would leave the
-// kernels of a second device at the 64 KiB default, so the record is kept per plan.
+// Dynamic LDS above 64 KiB has to be requested per kernel and per DEVICE.  The record is kept per plan (a plan lives on one
+// device; mra_plan_prepare reports its size) AND per (device, kernel) for the process, so that the second plan of a process - the
+// reference's MLE pattern builds a new MRATree per objective call - does not pay ~20 us per kernel again in its first pass.
+bool mra_big_lds_once(int device, const void* fn);      // mra_plan.hip: true the first time this (device, kernel) pair is seen
 static inline void ensure_big_lds(mra_plan* pl, std::initializer_list<const void*> fns) {
     for (const void* f : fns) {
         if (pl->big_lds_done.count(f)) continue;
-        if (!g_dry) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (!g_dry && mra_big_lds_once(pl->device, f)) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         pl->big_lds_done.insert(f);
     }
 }

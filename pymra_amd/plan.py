@@ -38,7 +38,7 @@ ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4
 # every symbol include/mra_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "mra_device_count", "mra_release_cached_memory", "mra_plan_create", "mra_plan_destroy", "mra_plan_set_locs", "mra_plan_set_obs",
-    "mra_plan_set_kernel", "mra_plan_set_locs_rows", "mra_plan_set_obs_rows", "mra_get_predict_rows", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
+    "mra_plan_set_kernel", "mra_plan_set_locs_rows", "mra_plan_set_obs_rows", "mra_get_predict_rows", "mra_get_predict_rows_sd", "mra_eval_kernel", "mra_plan_set_cov_block", "mra_run", "mra_get_likelihood", "mra_get_predict",
     "mra_get_buffer", "mra_get_node_block", "mra_get_timers", "mra_plan_set_option", "mra_plan_get_option", "mra_plan_prepare", "mra_kernel_family_count",
     "mra_get_kernel_stats", "mra_get_kernel_work", "mra_device_synchronize", "mra_plan_info", "mra_comm_unique_id", "mra_comm_init",
     "mra_plan_set_reduce_level", "mra_reduce_size", "mra_reduce_export", "mra_reduce_import",
@@ -84,6 +84,7 @@ def load_library():
         "mra_plan_set_locs_rows": (C.c_int, [vp, vp, vp]),
         "mra_plan_set_obs_rows": (C.c_int, [vp, vp, vp, vp, dbl]),
         "mra_get_predict_rows": (C.c_int, [vp, vp, vp, i64, vp, vp]),
+        "mra_get_predict_rows_sd": (C.c_int, [vp, vp, vp, i64, vp, vp, vp]),
         "mra_plan_set_kernel": (C.c_int, [vp, C.c_int, vp, C.c_int]),
         "mra_plan_set_cov_block": (C.c_int, [vp, i32, vp, i64, i64, vp]),
         "mra_eval_kernel": (C.c_int, [C.c_int, vp, C.c_int, vp, i64, vp]),
@@ -284,15 +285,17 @@ class HipPlan:
         self._check(self.lib.mra_get_likelihood(self._h, C.byref(d), C.byref(u)))
         return d.value, u.value
 
-    def predict(self):
-        """(mean[N], var[N]) in the caller's row order; rows outside every leaf report 0 (see
-        topology: rows that a partition drops, pyMRA/MRANode.py:222-228, 492-495)."""
+    def predict(self, with_sd=False):
+        """(mean[N], var[N]) in the caller's row order - with_sd: (mean, var, sd = sqrt(var)) -; rows outside every leaf report 0
+        (see topology: rows that a partition drops, pyMRA/MRANode.py:222-228, 492-495)."""
         t = self.topo
         _, perm, in_leaf = self._row_maps()
         mean = np.empty(t.N)
         var = np.empty(t.N)
-        self._check(self.lib.mra_get_predict_rows(self._h, _ptr(perm), _ptr(in_leaf), int(t.N), _ptr(mean), _ptr(var)))
-        return mean, var
+        sd = np.empty(t.N) if with_sd else None
+        self._check(self.lib.mra_get_predict_rows_sd(self._h, _ptr(perm), _ptr(in_leaf), int(t.N), _ptr(mean), _ptr(var),
+                                                     None if sd is None else _ptr(sd)))
+        return (mean, var, sd) if with_sd else (mean, var)
 
     def buffer(self, what):
         n = C.c_int64()
