@@ -451,6 +451,11 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt(const GemmProb* __restrict__
 //  flight while step k is on the MFMA pipe).  Halves the L1/L2 operand traffic per MFMA of the
 //  direct-load kernel above; same GemmProb, same epilogues.
 // ------------------------------------------------------------------------------------------------
+// the K dimension of a segmented product as a flat table of 16-column steps (built in LDS by the kernels that walk it)
+#define SB_MAXST 256     /* 16-column steps (and segments) per problem: K <= 4096 */
+struct SbStep { const double* A; int lda; int k0s; };                            // k0s: column offset of the step | sign bit of the segment
+#define SB_MAXST2 96
+struct SbStep2 { const double* A; const double* B; int lda, ldb, k0s, pad; };    // k_gemm_nt_lds (A and B sides; SB_MAXST2 steps)
 #ifndef GL_LDS_LD
 #define GL_LDS_LD 18      /* doubles per staged row: 16 + 2 pad -> conflict-free 32-byte fragment reads */
 #endif
@@ -460,6 +465,14 @@ template <int EPI, int DIM, int MODE>
 __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restrict__ probs, KernelParams kp, unsigned G, unsigned nprob, unsigned S = 1) {
     __shared__ __attribute__((aligned(16))) double sA[2][64 * GL_LDS_LD];
     __shared__ __attribute__((aligned(16))) double sB[2][64 * GL_LDS_LD];
+    constexpr bool SEGS = EPI == EPI_SET;
+    // SET with segments: the K steps as a flat table in LDS (see k_syrk_blk: walking the segment descriptors inside the loop reads
+    // them with vector loads and waits with vmcnt(0) - for the prefetches too - at every segment boundary)
+    // (SB_MAXST2 steps at most, the host checks: with 3 KB of table four workgroups still share a CU's LDS; the per-segment step
+    // counts sit in the not yet used stage while the table is built)
+    __shared__ __attribute__((aligned(16))) SbStep2 sTab[SEGS ? SB_MAXST2 : 1];
+    __shared__ int sNk;
+    int* const sK = (int*)&sA[0][0];
     unsigned prob_i, wg_i;
     if (!xcd_problem_tile(G, nprob, prob_i, wg_i, S)) return;
     const GemmProb pb = probs[prob_i];
@@ -486,37 +499,34 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     const d4 zero = {0, 0, 0, 0};
     d4 c00 = zero, c01 = zero, c10 = zero, c11 = zero;
     // SET: K may be split into segments (sum over a node's children, GemmSeg; `neg` segments are subtracted): the K loop below then
-    // walks a flat sequence of (segment, 16-column step) pairs, the prefetch running ahead across segment boundaries
-    constexpr bool SEGS = EPI == EPI_SET;
+    // walks the step table, the prefetch running ahead across segment boundaries
     const bool segmented = SEGS && pb.nseg > 0;
     int nk = pb.K >> 4;
-    int it_sg = 0, it_k = 0, it_K = pb.K;
-    bool it_neg = false, it_done = false;
-    auto seg_enter = [&](int s_) -> bool {                  // first segment >= s_ with K > 0
-        for (int sg = s_; sg < pb.nseg; ++sg) {
-            const GemmSeg* g = pb.segs + sg;
-            const int Ks = g->K;
-            if (Ks > 0) {
-                it_sg = sg; it_K = Ks; it_k = 0; it_neg = g->neg != 0;
-                ap = g->A + (a_ok ? arow : 0) * g->lda + sch;
-                bp = g->B + (b_ok ? brow : 0) * g->ldb + sch;
-                return true;
-            }
+    int it_s = 0, it_k = 0, it_sgn = 0;
+    if (SEGS && segmented) {
+        const int nseg = pb.nseg;
+        for (int sg = threadIdx.x; sg < nseg; sg += 256) sK[sg] = pb.segs[sg].K >> 4;
+        __syncthreads();
+        for (int sg = threadIdx.x; sg < nseg; sg += 256) {
+            int start = 0;
+            for (int j = 0; j < sg; ++j) start += sK[j];
+            const int cnt = sK[sg];
+            const GemmSeg g = pb.segs[sg];
+            for (int t = 0; t < cnt; ++t) sTab[start + t] = SbStep2{g.A, g.B, (int)g.lda, (int)g.ldb, (16 * t) | (g.neg ? (int)0x80000000 : 0), 0};
+            if (sg == nseg - 1) sNk = start + cnt;
         }
-        return false;
-    };
-    if (segmented) {
-        nk = 0;
-        for (int sg = 0; sg < pb.nseg; ++sg) nk += pb.segs[sg].K >> 4;
-        if (!seg_enter(0)) nk = 0;
+        __syncthreads();                                     // (also: sK is dead before the first stage is written)
+        nk = sNk;
+        if (nk <= 0) { ap = bp = (const double*)probs; nk = 0; }      // (no columns at all: the unconditional prefetches read something valid)
     }
-    auto seg_advance = [&]() {                               // one step on; past the end the last step is read again (unconditional loads)
-        if (it_done) return;
-        it_k += 16;
-        if (it_k >= it_K) {
-            const int kl = it_k - 16;
-            if (!seg_enter(it_sg + 1)) { it_done = true; it_k = kl; }
-        }
+    auto seg_fetch = [&]() {                                 // pointers of step it_s (past the end: the last step again); then one step on
+        if (nk <= 0) return;
+        const SbStep2 e = sTab[min(it_s, nk - 1)];
+        ap = e.A + (a_ok ? arow : 0) * e.lda + sch;
+        bp = e.B + (b_ok ? brow : 0) * e.ldb + sch;
+        it_k = e.k0s & 0x7fffffff;
+        it_sgn = e.k0s & (int)0x80000000;
+        ++it_s;
     };
     // Global loads run GL_PF K-steps ahead of the MFMAs through GL_PF register sets (statically indexed:
     // the loop is unrolled by GL_PF); the LDS stage is double-buffered.  What-if runs showed this
@@ -526,18 +536,18 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
     // LDS; steps past the end re-read the last step): a load inside a branch makes the compiler fall
     // back to s_waitcnt vmcnt(0) in the loop, which waits for the prefetches just issued as well.
     d4 ra[GL_PF], rb[GL_PF];
-    bool rn[GL_PF];
+    int rn[GL_PF];                              // sign bit of the segment the set was loaded from
     const int klast = (nk > 0 ? nk - 1 : 0) * 16;
 #pragma unroll
     for (int i = 0; i < GL_PF; ++i) {
         if (SEGS && segmented) {
-            ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_neg;
-            seg_advance();
+            seg_fetch();
+            ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_sgn;
         } else {
             const int ko = i < nk ? i * 16 : klast;
             ra[i] = gld4(ap + ko);
             rb[i] = gld4(bp + ko);
-            rn[i] = false;
+            rn[i] = 0;
         }
     }
     // SUB: the C tile this wave is going to update is fetched now, not after the K loop (sixteen
@@ -606,8 +616,8 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
             const int ks = ks0 + i;                        // LDS buffer i & 1 holds step ks (GL_PF is even)
             if (ks < nk) {
                 if (SEGS && segmented) {                   // register set i is free again: refill it GL_PF steps ahead
-                    ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_neg;
-                    seg_advance();
+                    seg_fetch();
+                    ra[i] = gld4(ap + it_k); rb[i] = gld4(bp + it_k); rn[i] = it_sgn;
                 } else {
                     const int ko = (ks + GL_PF < nk) ? (ks + GL_PF) * 16 : klast;
                     ra[i] = gld4(ap + ko);
@@ -686,6 +696,213 @@ __global__ __launch_bounds__(256, 4) void k_gemm_nt_lds(const GemmProb* __restri
         fetch_rows(m0 + 16);
         emit(c10, m0 + 16, n0, bc0, 2);
         if (nv1) emit(c11, m0 + 16, n0 + 16, bc1, 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Blocked segmented SYRK: C = [I] + sum_seg (+|-) A_seg A_seg^T (lower part) for fronts that do not fit in LDS
+//  (the grandparents' fronts of deep 64-wide trees: 464 x 464 from 20 segments, K = 768, at config 5).
+//  One workgroup (4 waves) per 96 x 96 block of 16 x 16 sub-tiles on or below the diagonal; the 96 + 96 operand
+//  rows of a 16-k step go through a double-buffered LDS stage (one barrier per step, global loads two steps
+//  ahead).  Against the 32 x 32 wave tiles of k_gemm_nt (every wave pulls its own 32 + 32 rows through L1 / L2
+//  per step: 4 flop per operand byte, the L2 -> CU path is the limit) a block moves 12 flop per byte, and only the
+//  sub-tiles on or below the diagonal are computed: off the diagonal a wave owns 3 x 3 sub-tiles (36 MFMAs per
+//  step and barrier), on it the 21 lower sub-tiles are dealt 6 / 5 / 5 / 5.
+//  Measured (tools/syrk_lab.hip, 4096 problems of config 5's shape): k_gemm_nt 21.4 ms, this kernel 13.0 ms = 54 TFLOP/s executed;
+//  its MFMAs alone 10.7 ms (the wave slots of the 6 / 5 / 5 / 5 deal at 2.2 GHz), its loads + LDS writes + barriers alone 5.0 ms.
+//  Layout of the stage: role 0 = the rows of block row bi (negated for `neg` segments on their way in), role 1 = the
+//  rows of block column bj (diagonal blocks load their rows twice - the second copy is an L1 hit - and run the same
+//  code).  Sub-tiles strictly above the diagonal are not written (k_gemm_nt wrote the upper half of its 32 x 32
+//  diagonal tiles; nothing reads it: k_panel_chol, k_front, k_assemble and the Schur products work on lower tiles).
+// ------------------------------------------------------------------------------------------------
+#define SB_T 6
+#define SB_ROWS (SB_T * 16)
+// VAR: what-if switches of tools/syrk_lab.hip (timing only, wrong results): 1 no barriers, 2 no global loads in the loop, 4 operand
+// fragments read from LDS once, 8 no LDS writes in the loop, 16 no MFMAs; 0 in the library
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(256, 2) void k_syrk_blk(const GemmProb* __restrict__ probs, unsigned G, unsigned nprob, unsigned S = 1) {
+    static_assert(EPI == EPI_SET, "k_syrk_blk: SET epilogue only");
+    __shared__ __attribute__((aligned(16))) double sR[2][2 * SB_ROWS * GL_LDS_LD];
+    __shared__ __attribute__((aligned(16))) SbStep sTab[SB_MAXST];
+    __shared__ int sK[SB_MAXST];
+    __shared__ int sNk;
+    unsigned prob_i, wg_i;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i, S)) return;
+    const GemmProb* __restrict__ pp = probs + __builtin_amdgcn_readfirstlane(prob_i);
+    const int M = pp->M, Mt = M >> 4;
+    const int nbk = (Mt + SB_T - 1) / SB_T;
+    const int tile = __builtin_amdgcn_readfirstlane((int)wg_i);
+    if (tile >= nbk * (nbk + 1) / 2) return;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+    const int bj = tile - bi * (bi + 1) / 2;
+    const bool diag = bi == bj;
+    const int nri = min(SB_T, Mt - SB_T * bi);              // sub-tile rows of this block row that exist
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    // ---- staging role: thread -> three (role, row, 32-byte chunk) slots of the 192-row stage
+    const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) << 2;
+    long grow[3];
+    int lofs[3];
+    bool sneg[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int f = srow + 64 * i, role = f >= SB_ROWS ? 1 : 0, row = f - role * SB_ROWS;
+        grow[i] = min((role ? bj : bi) * SB_ROWS + row, M - 1);          // rows past the end re-read the last one: their sub-tiles are never written
+        lofs[i] = (role * SB_ROWS + row) * GL_LDS_LD + sch;
+        sneg[i] = role == 0;
+    }
+    // ---- the K dimension as a flat table of 16-column steps in LDS: (operand base, leading dimension, column offset | sign).  Walking
+    // the segment descriptors inside the loop (as k_gemm_nt does) reads them with VECTOR loads - the compiler cannot prove the walk
+    // uniform - and every segment boundary then waits with s_waitcnt vmcnt(0) for the prefetches just issued as well.
+    const GemmSeg* __restrict__ segs = pp->segs;
+    const int nseg = pp->nseg;
+    for (int sg = threadIdx.x; sg < nseg; sg += 256) sK[sg] = segs[sg].K >> 4;
+    __syncthreads();
+    for (int sg = threadIdx.x; sg < nseg; sg += 256) {
+        int start = 0;
+        for (int j = 0; j < sg; ++j) start += sK[j];
+        const int cnt = sK[sg];
+        const double* A = segs[sg].A;
+        const int lda = (int)segs[sg].lda, sgn = segs[sg].neg ? (int)0x80000000 : 0;
+        for (int t = 0; t < cnt; ++t) sTab[start + t] = SbStep{A, lda, (16 * t) | sgn};
+        if (sg == nseg - 1) sNk = start + cnt;
+    }
+    __syncthreads();
+    const int nk = __builtin_amdgcn_readfirstlane(nseg > 0 ? sNk : 0);
+    int growi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) growi[i] = (int)grow[i];
+    int it_s = 0;                                            // next step to load
+    auto issue = [&](d4* dst, int& sgn) {                    // loads of step it_s (past the end: the last step again, unconditional loads)
+        const SbStep e = sTab[min(it_s, nk - 1)];
+        const double* base = e.A + (e.k0s & 0x7fffffff) + sch;
+        sgn = e.k0s & (int)0x80000000;
+        if (!(VAR & 2)) {
+            dst[0] = gld4(base + (long)growi[0] * e.lda); dst[1] = gld4(base + (long)growi[1] * e.lda); dst[2] = gld4(base + (long)growi[2] * e.lda);
+        }
+        ++it_s;
+    };
+    auto flip = [&](const d4 v, int sgn) -> d4 {              // v with the sign bit of every element XORed with sgn (0 or 0x80000000)
+        d4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __hiloint2double(__double2hiint(v[e]) ^ sgn, __double2loint(v[e]));
+        return o;
+    };
+    const d4 zero = {0, 0, 0, 0};
+    d4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = zero;
+    // roles of the wave: off the diagonal sub-tile rows 3 wr .. 3 wr + 2 x columns 3 wc .. 3 wc + 2; on it row rowA with
+    // columns 0 .. nA - 1 (accumulators 0 ..) and row rowB with columns 0 .. nB - 1 (accumulators 6, 7)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nvr = diag ? 0 : max(0, min(3, nri - 3 * wr));
+    int rowA = 5 - wave, nA = 6 - wave, rowB = wave == 2 ? 0 : 1, nB = wave < 2 ? 0 : wave - 1;
+    if (!diag || rowA >= nri) nA = 0;
+    if (!diag || rowB >= nri) nB = 0;
+    // the K loop, once for blocks on the diagonal and once for the others (two loops, not one loop with both bodies: the register
+    // allocation of the union spilled)
+    auto kloop = [&](auto on_diag) {
+        constexpr bool DG = decltype(on_diag)::value;
+        d4 ra[GL_PF][3];
+        int rn[GL_PF];
+#pragma unroll
+        for (int i = 0; i < GL_PF; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ra[i][j] = zero;
+            issue(ra[i], rn[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *(d4*)(&sR[0][lofs[j]]) = flip(ra[0][j], sneg[j] ? rn[0] : 0);
+        __syncthreads();
+        const int fo = r * GL_LDS_LD + 4 * q;
+        for (int ks0 = 0; ks0 < nk; ks0 += GL_PF) {
+#pragma unroll
+            for (int i = 0; i < GL_PF; ++i) {
+                const int ks = ks0 + i;                        // LDS buffer i & 1 holds step ks (GL_PF is even)
+                if (ks < nk) {
+                    issue(ra[i], rn[i]);
+                    const double* sA = &sR[(VAR & 4) ? 0 : (i & 1)][(VAR & 4) ? 0 : fo];
+                    const double* sB = sA + SB_ROWS * GL_LDS_LD;
+                    if (!DG) {
+                        if (nvr > 0) {
+                            d4 a[3], b[3];
+#pragma unroll
+                            for (int x = 0; x < 3; ++x) {
+                                a[x] = *(const d4*)(sA + (3 * wr + x) * 16 * GL_LDS_LD);
+                                b[x] = *(const d4*)(sB + (3 * wc + x) * 16 * GL_LDS_LD);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int x = 0; x < 3; ++x)
+                                    if (x < nvr) {
+#pragma unroll
+                                        for (int y = 0; y < 3; ++y) acc[3 * x + y] = (VAR & 16) ? acc[3 * x + y] : mfma16(a[x][j], b[y][j], acc[3 * x + y]);
+                                    }
+                        }
+                    } else if ((nA | nB) != 0) {
+                        const d4 aA = *(const d4*)(sA + rowA * 16 * GL_LDS_LD);
+                        const d4 aB = *(const d4*)(sA + rowB * 16 * GL_LDS_LD);
+                        // columns in two halves of three (three B fragments live at a time; three independent accumulator chains)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if (h == 0 || 3 < nA) {
+                                d4 b[3];
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) b[c] = *(const d4*)(sB + (3 * h + c) * 16 * GL_LDS_LD);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c)
+                                        if (3 * h + c < nA) acc[3 * h + c] = (VAR & 16) ? acc[3 * h + c] : mfma16(aA[j], b[c][j], acc[3 * h + c]);
+                                    if (h == 0) {
+#pragma unroll
+                                        for (int c = 0; c < 2; ++c)
+                                            if (c < nB) acc[6 + c] = (VAR & 16) ? acc[6 + c] : mfma16(aB[j], b[c][j], acc[6 + c]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (!(VAR & 8))
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        *(d4*)(&sR[(i + 1) & 1][lofs[j]]) = flip(ra[(i + 1) % GL_PF][j], sneg[j] ? rn[(i + 1) % GL_PF] : 0);
+                    if (!(VAR & 1)) __syncthreads();
+                }
+            }
+        }
+    };
+    if (nk > 0) {
+        if (diag) kloop(std::true_type{});
+        else kloop(std::false_type{});
+    }
+    // ---- epilogue: accumulator element s of lane (r,q) is C[row0 + q + 4 s][col0 + r]
+    double* const C = pp->C;
+    const long ldc = pp->ldc;
+    const int done = pp->diag_one;
+    auto emit = [&](const d4 v, int ti, int tj) {
+        const int row0 = (SB_T * bi + ti) * 16, col = (SB_T * bj + tj) * 16 + r;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int row = row0 + q + 4 * s4;
+            gst(C + (long)row * ldc + col, v[s4] + ((row == col && row < done) ? 1.0 : 0.0));
+        }
+    };
+    if (!diag) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            if (x < nvr) {
+#pragma unroll
+                for (int y = 0; y < 3; ++y) emit(acc[3 * x + y], 3 * wr + x, 3 * wc + y);
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (c < nA) emit(acc[c], rowA, c);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nB) emit(acc[6 + c], rowB, c);
     }
 }
 

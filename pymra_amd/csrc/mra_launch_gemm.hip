@@ -59,6 +59,25 @@ static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) 
 #undef MRA_LG_LAUNCH
 }
 
+// blocked segmented SYRK (k_syrk_blk): every problem is C = [I] + sum_seg (+|-) A_seg A_seg^T with .lower set, M == N == a multiple of 16,
+// nseg > 0 and A == B in every segment
+void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M) {
+    if (!nprob || M <= 0) return;
+    const long nbk = (M / 16 + SB_T - 1) / SB_T;
+    const unsigned gx = (unsigned)(nbk * (nbk + 1) / 2);
+    const size_t chunk = (size_t)std::max<long>(8, ((0x7fffffffL / (long)gx) / 8) * 8);
+    for (size_t off = 0; off < nprob; off += chunk) {
+        unsigned gy = (unsigned)std::min<size_t>(chunk, nprob - off);
+        unsigned S = 1, gxs = gx;
+        if (gy < 8u && gx >= 8u) {
+            S = gy == 1 ? 8u : (gy == 2 ? 4u : (gy <= 4 ? 2u : 1u));
+            gxs = (gx + S - 1) / S;
+            gy *= S;
+        }
+        hipLaunchKernelGGL((k_syrk_blk<EPI_SET>), dim3(gxs * (((gy + 7u) / 8u) * 8u)), dim3(256), 0, pl->stream, probs + off, gxs, gy, S);
+    }
+}
+
 void mra_launch_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds, bool lower_tri) {
     switch (epi) {
         case EPI_SET: launch_gemm<EPI_SET>(pl, probs, nprob, maxM, maxN, allow_lds, lower_tri); break;

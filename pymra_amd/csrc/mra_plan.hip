@@ -864,6 +864,13 @@ static void build_leaf(mra_plan* pl, const double* y) {
                 pl->fl_parent_panel += Work(2.0 * (rkt + nat) * rkt * kobs, 2.0 * lv.nf * lv.cw * kpad, 8.0 * (lv.nf * kpad + (double)lv.nf * lv.cw));
             }
             pl->gParentPanel.upload(pp);
+            // the LDS-tiled segmented product keeps its K steps as a table of SB_MAXST2 entries
+            pl->parent_panel_lds_ok = true;
+            for (size_t sidx = 0; sidx < lv.nodes.size() && pl->parent_panel_lds_ok; ++sidx) {
+                long steps = 0;
+                for (int k = 0; k < where[sidx].second; ++k) steps += segs_ao[where[sidx].first + k].K / 16;
+                if (where[sidx].second > SB_MAXST2 || steps > SB_MAXST2) pl->parent_panel_lds_ok = false;
+            }
             pl->gParentOwn.upload(pown);
             pl->gParentZt.upload(pzt);
             {
@@ -906,6 +913,13 @@ static void build_leaf(mra_plan* pl, const double* y) {
                 gp[sidx] = g;
             }
             pl->gGrandSyrk.upload(gp);
+            // k_syrk_blk keeps the K steps of a problem as a table in LDS: SB_MAXST segments / 16-column steps at most
+            pl->grand_syrk_blk_ok = (lg.nf % 16) == 0;
+            for (size_t sidx = 0; sidx < lg.nodes.size() && pl->grand_syrk_blk_ok; ++sidx) {
+                long steps = 0;
+                for (int k = 0; k < gwhere[sidx].second; ++k) steps += gsegs[gwhere[sidx].first + k].K / 16;
+                if (gwhere[sidx].second == 0 || gwhere[sidx].second > SB_MAXST || steps > SB_MAXST) pl->grand_syrk_blk_ok = false;
+            }
         }
         {
             std::vector<FrontProb> pf(lv.nodes.size());
@@ -1376,7 +1390,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                         KTimer kt(pl, KF_LEAF_SYRK, pl->fl_parent_panel);
                         if (lvp.cwt <= 4) hipLaunchKernelGGL(k_parent_front<2>, dim3((unsigned)nnp), dim3(512), pl->parent_own_lds, pl->stream, pl->gParentOwn.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p);
                         else hipLaunchKernelGGL(k_parent_front<4>, dim3((unsigned)nnp), dim3(512), pl->parent_own_lds, pl->stream, pl->gParentOwn.p, pl->parentSegs.p, pl->dnode.p, pl->errflag.p);
-                        launch_gemm<EPI_SET>(pl, pl->gParentPanel.p, nnp, lvp.na, lvp.cw, pl->seg_gemm_lds, false);
+                        launch_gemm<EPI_SET>(pl, pl->gParentPanel.p, nnp, lvp.na, lvp.cw, pl->seg_gemm_lds && pl->parent_panel_lds_ok, false);
                     }
                     {
                         KTimer kt(pl, KF_FRONT_CHOL, pl->lev[m].fl_fchol.with_bytes(8.0 * 2 * nnp * (double)lvp.na * lvp.cw));
@@ -1391,7 +1405,8 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 if (is_red) throw MraError(MRA_ERR_STATE, "the reduce level cannot be the level above panel-only fronts");
                 const LevelData& lg = pl->lev[m];
                 KTimer kt(pl, KF_FRONT_SCHUR, pl->fl_grand_syrk);
-                launch_gemm<EPI_SET>(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, lg.nf, false, true);      // (LDS-tiled: 24.2 vs 23.7 ms at config 5)
+                if (pl->use_syrk_blk && pl->grand_syrk_blk_ok) mra_launch_syrk_blk(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf);
+                else launch_gemm<EPI_SET>(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, lg.nf, false, true);      // (64 x 64 LDS-tiled: 24.2 vs 23.7 ms at config 5)
             } else if (is_red) {
                 // (the rank-local log-det sum of everything below rides in the same launch, see the reduce block)
                 LevelData& lvr = pl->lev[m];
@@ -2243,6 +2258,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 10) { pl->leaf_solve_split = value == 2 ? 2 : 1; return MRA_OK; }
     if (option == 11) { pl->use_chol_lds = (int)value; return MRA_OK; }
     if (option == 12) { pl->seg_gemm_lds = value != 0; return MRA_OK; }
+    if (option == 14) { pl->use_syrk_blk = value != 0; return MRA_OK; }
     if (option == 13) { pl->ut_gather = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
@@ -2273,6 +2289,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 10: *value = pl->leaf_solve_split; break;
         case 11: *value = pl->use_chol_lds; break;
         case 12: *value = pl->seg_gemm_lds; break;
+        case 14: *value = pl->use_syrk_blk; break;
         case 13: *value = pl->ut_gather; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));

@@ -287,6 +287,9 @@ struct mra_plan {
     size_t n_chol_small = 0;
     bool ut_gather = true;                    // fused path: the leaves' Ut rows gathered from W by the row solve (no scatter in the row cascade: 1.21 -> 1.03 ms there, +0.16 ms in the solve)
     bool cphantom_valid = false;              // the phantom observation rows of the leaves' C blocks hold their identity rows
+    bool parent_panel_lds_ok = false;         // every parent-panel problem fits the step table of the LDS-tiled segmented product
+    bool grand_syrk_blk_ok = false;           // every grandparent problem fits k_syrk_blk's step table
+    bool use_syrk_blk = true;                 // the grandparents' signed SYRK on 96 x 96 blocks through LDS (k_syrk_blk) instead of 32 x 32 wave tiles (option 14)
     bool seg_gemm_lds = true;                 // the parents' panel product (segmented: sum over the children's Ut blocks) on the LDS-tiled GEMM (6.3 -> 5.4 ms at config 5)
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
     DevVec<long> leaf_row0_dev;
@@ -402,6 +405,7 @@ static inline void ensure_big_lds(mra_plan* pl, std::initializer_list<const void
 // batched C (=|-=) f(A B^T) with epilogue EPI_SET / EPI_SUB / EPI_COV / EPI_HOSTCOV; lower_tri: every problem has .lower set and M == N
 void mra_launch_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true, bool lower_tri = false);
 void mra_launch_leaf_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob);
+void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M);
 void launch_cascade_d1(mra_plan* pl, const CascadeArgs& ar);       // one translation unit per spatial dimension
 void launch_cascade_d2(mra_plan* pl, const CascadeArgs& ar);
 void launch_knot_chain_d1(mra_plan* pl, const KnotChainArgs& ka);

@@ -26,7 +26,7 @@ PRODUCTION = [
     # shards (at most two leaves per CU) and config 5
     r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
     r"k_predict_cascade<2, 6, 4, true, 3>", r"k_predict_cascade<2, 6, 4, false, 3>", r"k_predict_cascade<4, 4, 8, false, 1>",
-    r"k_parent_front<12>",
+    r"k_parent_front<12>", r"k_syrk_blk<0, 0>",
 ]
 # production kernels with a known, pinned amount of scratch: (pattern, exact bytes per lane)
 PINNED = []      # (round 4: k_parent_front<12> lost its 36 B with the blocked factorisation atom, the predictive cascades theirs with half staging)
