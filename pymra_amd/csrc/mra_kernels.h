@@ -260,6 +260,11 @@ struct GemmProb {
     // identity on phantoms: the leaves' C = v_m(o,o) + R I in likelihood-only runs
     const int* idxA;
     int sym_diag;
+    // k_leaf_gemm<..., SOLVE>: the row solve rides on the COV epilogue, C = (kernel - A B^T) L^-T with the N x N lower factor solveL
+    // (row-major, ld = N) and its inverted 16 x 16 diagonal blocks solveI; var[row] -= |C[row]|^2
+    const double* solveL;
+    const double* solveI;
+    double* var;
 };
 struct GemmSeg { const double* A; const double* B; long lda, ldb; int K; int neg; };   // neg: the segment is SUBTRACTED (k_gemm_nt only)
 
@@ -923,11 +928,35 @@ __global__ __launch_bounds__(256, 2) void k_syrk_blk(const GemmProb* __restrict_
 // NTHR threads per workgroup, WPE waves per SIMD the register budget is cut for (the second __launch_bounds__ argument is
 // waves per SIMD on HIP): <2, 7, 256, 2> holds 2 x 7 accumulators per wave at two waves per SIMD; <1, 7, 512, 4> one row
 // tile per wave at 128 registers, two 8-wave workgroups = four waves per SIMD
-template <int EPI, int DIM, int MODE, int RT, int CT, int NTHR, int WPE>
+// SOLVE (COV, N <= CT * 16 <= 64: one pass): the prior of one level of the level-by-level path in one launch - residual product,
+// kernel evaluation and the row solve W^m = R L^-T (MRANode.py:83-91) on the accumulators in vec layout, the way the cascades do it:
+//     x_jb = (r_jb - sum_{kb < jb} x_kb L[jb][kb]^T) inv_jb^T ,   var -= |x|^2 .
+// The factor's strictly-lower tiles (jb (jb-1)/2 + kb) and inverted diagonal blocks (6 + jb) sit in LDS as 16 x 16 tiles.  Against
+// k_gemm_nt_lds<COV> + k_trsm_rows2 the residual never visits HBM (one write of 64 columns and one read less per level).
+__device__ __forceinline__ int pp_N(const GemmProb* __restrict__ probs) { return probs[blockIdx.x].N; }
+template <int EPI, int DIM, int MODE, int RT, int CT, int NTHR, int WPE, int SOLVE = 0>
 __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restrict__ probs, KernelParams kp) {
+    static_assert(!SOLVE || (EPI == EPI_COV && CT <= 4), "k_leaf_gemm: the row solve rides on the COV epilogue of at most four column tiles");
     __shared__ __attribute__((aligned(16))) double sB[2][CT * 16 * LG_LD];
     __shared__ double sXB[CT * 16 * DIM];
     __shared__ int sIB[CT * 16];
+    __shared__ __attribute__((aligned(16))) double sL[SOLVE ? 10 * 256 : 2];
+    if (SOLVE) {
+        // factor tiles of this problem's node: staged once (the barrier in front of the first K loop covers them)
+        const int nct = (pp_N(probs) + 15) >> 4;
+        const double* L = probs[blockIdx.x].solveL;
+        const double* I = probs[blockIdx.x].solveI;
+        const long ldl = probs[blockIdx.x].N;
+        for (int e = threadIdx.x; e < 10 * 128; e += NTHR) {
+            const int tile = e >> 7, rr = (e >> 3) & 15, c2 = (e & 7) << 1;
+            d2 v = d2{0.0, 0.0};
+            if (tile < 6) {
+                const int jb = tile < 1 ? 1 : (tile < 3 ? 2 : 3), kb = tile - jb * (jb - 1) / 2;
+                if (jb < nct) v = gld2(L + (long)(jb * 16 + rr) * ldl + kb * 16 + c2);
+            } else if (tile - 6 < nct) v = gld2(I + (long)(tile - 6) * 256 + rr * 16 + c2);
+            *(d2*)(sL + tile * 256 + rr * 16 + c2) = v;
+        }
+    }
     const GemmProb* __restrict__ pp = probs + blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwave = blockDim.x >> 6;                           // 4: two workgroups (two leaves) share a CU, one's epilogue
@@ -1051,6 +1080,44 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
                     for (int c = 0; c < DIM; ++c) xa[c] = gld(pp->XA + row * DIM + c);
                 }
                 if (EPI == EPI_COV || EPI == EPI_HOSTCOV) op = pp->rowmap ? gldi(pp->rowmap + row) : -1;
+                if (SOLVE) {
+                    d4 x[CT];
+                    double ssq = 0.0;
+                    const int fo = prow * 16 + 4 * qe;
+#pragma unroll
+                    for (int jb = 0; jb < CT; ++jb) {
+                        if (jb < nc) {
+                            d4 v;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                const int lc = jb * 16 + 4 * qe + s4;
+                                const double cv = cov_of_dist2<MODE>(kp, pair_dist2<DIM>(xa, &sXB[lc * DIM], kp.circular));
+                                v[s4] = sIB[lc] < 0 ? 0.0 : cv - acc[h][jb][s4];
+                            }
+                            d4 upd = zero;
+#pragma unroll
+                            for (int kb = 0; kb < CT; ++kb) {
+                                if (kb < jb) {
+                                    const d4 a = *(const d4*)(sL + (jb * (jb - 1) / 2 + kb) * 256 + fo);
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4) upd = mfma16(a[s4], x[kb][s4], upd);
+                                }
+                            }
+                            v -= upd;
+                            const d4 ia = *(const d4*)(sL + (6 + jb) * 256 + fo);
+                            d4 xx = zero;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) xx = mfma16(ia[s4], v[s4], xx);
+                            x[jb] = xx;
+                            ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
+                            gst4(C + row * ldc + jb * 16 + 4 * qe, xx);
+                        }
+                    }
+                    ssq += __shfl_xor(ssq, 16, 64);
+                    ssq += __shfl_xor(ssq, 32, 64);
+                    if (qe == 0 && pp->var) { double* vp = pp->var + row; gst(vp, gld(vp) - ssq); }
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     if (j < nc) {

@@ -78,6 +78,21 @@ void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long
     }
 }
 
+// one level of the level-by-level prior in one launch (k_leaf_gemm<COV, ..., SOLVE>): problems are blocks of rows of a node, N = the
+// node's block width (<= 64), solveL / solveI its factor.  Two row tiles per wave, four waves: 32 MFMAs per wave, chunk and barrier.
+#ifndef MRA_PL_WPE
+#define MRA_PL_WPE 3
+#endif
+void mra_launch_prior_level(mra_plan* pl, const GemmProb* probs, size_t nprob) {
+    if (!nprob) return;
+    const int mode = pl->kp.mode;
+    const dim3 grid((unsigned)nprob);
+#define MRA_PL_LAUNCH(D, MD) hipLaunchKernelGGL((k_leaf_gemm<EPI_COV, D, MD, 2, 4, 256, (MD == 3 ? 2 : MRA_PL_WPE), 1>), grid, dim3(256), 0, pl->stream, probs, pl->kp)
+    if (pl->d == 1) { if (mode == 0) MRA_PL_LAUNCH(1, 0); else if (mode == 1) MRA_PL_LAUNCH(1, 1); else if (mode == 2) MRA_PL_LAUNCH(1, 2); else MRA_PL_LAUNCH(1, 3); }
+    else { if (mode == 0) MRA_PL_LAUNCH(2, 0); else if (mode == 1) MRA_PL_LAUNCH(2, 1); else if (mode == 2) MRA_PL_LAUNCH(2, 2); else MRA_PL_LAUNCH(2, 3); }
+#undef MRA_PL_LAUNCH
+}
+
 void mra_launch_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds, bool lower_tri) {
     switch (epi) {
         case EPI_SET: launch_gemm<EPI_SET>(pl, probs, nprob, maxM, maxN, allow_lds, lower_tri); break;

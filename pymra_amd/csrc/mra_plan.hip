@@ -413,6 +413,34 @@ static void build_static(mra_plan* pl) {
             lv.front_lds = lv.front_mode == 2 ? full : panel;
             lv.gFront.upload(fr);
         }
+        // one-launch prior of the level: blocks <= 64 wide (four column tiles in registers)
+        lv.prior_level_ok = lv.cw <= 64 && lv.cw % 16 == 0;
+        lv.fl_knot_resid = Work();
+        if (lv.prior_level_ok) {
+            std::vector<GemmProb> kn(nn), fz;
+            const long blk = 512;                            // rows per workgroup: four passes of 4 waves x 2 row tiles
+            for (size_t s = 0; s < nn; ++s) {
+                const int i = lv.nodes[s];
+                const long r0 = pl->row0[i], nr = pl->row1[i] - r0;
+                double* Lp = lv.Lp.p + s * (size_t)lv.cw * lv.cw;
+                const int* kix = pl->knot_idx.p + pl->knot_idx_off[i];
+                GemmProb c{};
+                c.A = pl->W.p + lv.a0; c.lda = pl->ldw; c.idxA = kix; c.B = c.A; c.ldb = pl->ldw; c.idxB = kix;
+                c.C = Lp; c.ldc = lv.cw; c.XA = pl->X.p; c.XB = pl->X.p;
+                c.M = lv.cw; c.N = lv.cw; c.K = Kanc; c.lower = 0; c.sym_diag = 1; c.diag_add = 0.0;
+                kn[s] = c;
+                const double rkt = (double)(pl->knot_ptr[i + 1] - pl->knot_ptr[i]), anct = (double)pl->anc_rank[i];
+                lv.fl_knot_resid += Work(2.0 * rkt * rkt * anct, 2.0 * lv.cw * lv.cw * Kanc, 8.0 * (rkt * (Kanc + pl->d) + (double)lv.cw * lv.cw));
+                for (long b0 = 0; b0 < nr; b0 += blk) {
+                    GemmProb g = resid[s];
+                    g.A += b0 * pl->ldw; g.C += b0 * pl->ldw; g.XA += b0 * pl->d;
+                    g.M = (int)std::min(blk, nr - b0);
+                    g.solveL = Lp; g.solveI = lv.invP.p + s * (size_t)lv.cwt * 256; g.var = pl->var.p + r0 + b0;
+                    fz.push_back(g);
+                }
+            }
+            lv.gKnotResid.upload(kn); lv.gResidFused.upload(fz);
+        }
         lv.hResid = resid;
         lv.gResid.upload(resid); lv.gSchur.upload(schur); lv.gUpdate.upload(upd); lv.gKinv.upload(kinv);
         lv.gPriorChol.upload(pch); lv.gFrontChol.upload(fch); lv.gTrsmPrior.upload(tpr); lv.gTrsmPost.upload(tpo);
@@ -1589,6 +1617,14 @@ static void run_all(mra_plan* pl, uint32_t flags) {
         LevelData& lv = pl->lev[m];
         const size_t nn = lv.nodes.size();
         if (!nn) continue;
+        if (pl->use_prior_level && lv.prior_level_ok && !pl->host_cov && pl->gemm_lds) {
+            // knots' residual block -> Lp (both sides gathered), its Cholesky, then residual + kernel + row solve of every row in one
+            // launch: the residual never visits HBM
+            { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_knot_resid); launch_gemm<EPI_COV>(pl, lv.gKnotResid.p, nn, lv.cw, lv.cw); }
+            { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
+            { KTimer kt(pl, KF_PRIOR_RESID, lv.fl_resid + lv.fl_trsm.with_bytes(0.0)); mra_launch_prior_level(pl, lv.gResidFused.p, lv.gResidFused.n); }
+            continue;
+        }
         {
             KTimer kt(pl, KF_PRIOR_RESID, lv.fl_resid);
             if (pl->host_cov) launch_gemm<EPI_HOSTCOV>(pl, lv.gResid.p, nn, lv.max_rows, lv.cw);
@@ -2259,6 +2295,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 11) { pl->use_chol_lds = (int)value; return MRA_OK; }
     if (option == 12) { pl->seg_gemm_lds = value != 0; return MRA_OK; }
     if (option == 14) { pl->use_syrk_blk = value != 0; return MRA_OK; }
+    if (option == 15) { pl->use_prior_level = value != 0; return MRA_OK; }
     if (option == 13) { pl->ut_gather = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
@@ -2290,6 +2327,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 11: *value = pl->use_chol_lds; break;
         case 12: *value = pl->seg_gemm_lds; break;
         case 14: *value = pl->use_syrk_blk; break;
+        case 15: *value = pl->use_prior_level; break;
         case 13: *value = pl->ut_gather; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));

@@ -78,8 +78,8 @@ static const char* kfam_name[3][KF_COUNT] = {
      "k_trsm_rows2 predict (unused on the fused path)",
      "k_predict_cascade (leaf update + all levels, mean/var)",
      "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"},
-    {"k_gemm_nt_lds<COV> prior residual per level",
-     "k_panel_chol prior kInv Cholesky per level",
+    {"k_leaf_gemm<COV,SOLVE> prior of a level: residual + kernel + row solve (or k_gemm_nt_lds<COV> residual only)",
+     "k_gemm_nt_lds<COV> knots' residual block + k_panel_chol prior kInv Cholesky per level",
      "k_trsm_rows2 prior W = R L^-T per level",
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
@@ -90,8 +90,8 @@ static const char* kfam_name[3][KF_COUNT] = {
      "k_trsm_rows2 predict X = W Lt^-T per level",
      "k_gemm_nt_lds<SUB> predict update per level",
      "small kernels (k_assemble, k_gather_kinv, k_leaf_moments, k_sum_dnode, ...)"},
-    {"k_gemm_nt_lds<COV> prior residual per level",
-     "k_panel_chol prior kInv Cholesky per level",
+    {"k_leaf_gemm<COV,SOLVE> prior of a level: residual + kernel + row solve (or k_gemm_nt_lds<COV> residual only)",
+     "k_gemm_nt_lds<COV> knots' residual block + k_panel_chol prior kInv Cholesky per level",
      "k_trsm_rows2 prior W = R L^-T per level",
      "k_leaf_gemm<COV> leaf residual V[S,o] and C",
      "k_chol_wave + k_trsm_rows2 (or k_panel_chol) leaf factor and solves",
@@ -208,6 +208,11 @@ struct LevelData {
     long max_rows = 0;               // largest row range among the nodes
     DevVec<double> Lp, invP, F, invF;
     DevVec<GemmProb> gResid, gSchur, gUpdate;
+    // one-launch prior of the level (k_leaf_gemm<COV, SOLVE>): the knots' residual block straight into Lp (both sides gathered through
+    // the knot list), then residual + kernel + row solve on blocks of rows
+    DevVec<GemmProb> gKnotResid, gResidFused;
+    bool prior_level_ok = false;
+    Work fl_knot_resid;
     std::vector<GemmProb> hResid;
     DevVec<KinvProb> gKinv;
     DevVec<PanelProb> gPriorChol, gFrontChol;
@@ -287,6 +292,7 @@ struct mra_plan {
     size_t n_chol_small = 0;
     bool ut_gather = true;                    // fused path: the leaves' Ut rows gathered from W by the row solve (no scatter in the row cascade: 1.21 -> 1.03 ms there, +0.16 ms in the solve)
     bool cphantom_valid = false;              // the phantom observation rows of the leaves' C blocks hold their identity rows
+    bool use_prior_level = true;              // levels of the level-by-level prior with blocks <= 64 wide: residual + kernel + row solve in one launch (option 15)
     bool parent_panel_lds_ok = false;         // every parent-panel problem fits the step table of the LDS-tiled segmented product
     bool grand_syrk_blk_ok = false;           // every grandparent problem fits k_syrk_blk's step table
     bool use_syrk_blk = true;                 // the grandparents' signed SYRK on 96 x 96 blocks through LDS (k_syrk_blk) instead of 32 x 32 wave tiles (option 14)
@@ -406,6 +412,7 @@ static inline void ensure_big_lds(mra_plan* pl, std::initializer_list<const void
 void mra_launch_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true, bool lower_tri = false);
 void mra_launch_leaf_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob);
 void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M);
+void mra_launch_prior_level(mra_plan* pl, const GemmProb* probs, size_t nprob);
 void launch_cascade_d1(mra_plan* pl, const CascadeArgs& ar);       // one translation unit per spatial dimension
 void launch_cascade_d2(mra_plan* pl, const CascadeArgs& ar);
 void launch_knot_chain_d1(mra_plan* pl, const KnotChainArgs& ka);

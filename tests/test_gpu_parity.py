@@ -805,6 +805,15 @@ def test_deep_wide_trees_two_kernel_predictive_cascade(hip, n, r, M, oracle):
     m3, v3 = pl.predict()
     assert abs(d + u - lik) <= 1e-13 * abs(lik)
     assert np.max(np.abs(m3 - mean)) < 1e-11 and K.rel(np.sqrt(v3), np.sqrt(var)) < 1e-10
+    # the prior of a level in one launch (knots' residual block -> Lp, then residual + kernel + row solve: k_leaf_gemm<COV, SOLVE>,
+    # the default) against residual product, gather, factorisation and row solve as four launches
+    assert pl.get_option(15) == 1
+    pl.set_option(14, 1); pl.set_option(15, 0)
+    pl.run(True, True)
+    d, u = pl.likelihood()
+    m4, v4 = pl.predict()
+    assert abs(d + u - lik) <= 1e-12 * abs(lik)
+    assert np.max(np.abs(m4 - mean)) < 1e-10 and K.rel(np.sqrt(v4), np.sqrt(var)) < 1e-9
     pl.close()
     if oracle:
         ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(K.ROOT, "tools"))
 # kernels launched by a likelihood+predict pass of BASELINE config 3 (fused path, 2-D, Matern32 = mode 0) and of config 5
 # (level-by-level path), sharded or not
 PRODUCTION = [
-    r"k_knot_chain<2, 8, 2, 0>", r"k_prior_cascade<2, 8, 2, 0, true>", r"k_leaf_gemm<2, 2, 0, 1, 8, 512, 4>",
+    r"k_knot_chain<2, 8, 2, 0>", r"k_prior_cascade<2, 8, 2, 0, true>", r"k_leaf_gemm<2, 2, 0, 1, 8, 512, 4, 0>",
     r"k_chol_wave<12>", r"k_trsm_rows2<8>", r"k_trsm_rows2<12>", r"k_front<true>", r"k_leaf_solve_update<8, 13, true>",
     r"k_gemm_nt_lds<2, 2, 0>", r"k_gemm_nt_lds<1, 2, 0>", r"k_gemm_nt<0, 2, 0>", r"k_gemm_nt<1, 2, 0>", r"k_panel_chol",
     r"k_trsm_rows2<4>", r"k_front<false>", r"k_sum_dnode", r"k_leaf_cphantom", r"k_assemble", r"k_leaf_moments",
@@ -38,6 +38,9 @@ ALLOWED = [
     (r"k_leaf_gemm<2, \d, 3,", 544, "ocml sincos stack"),
     (r"k_gemm_nt(_lds)?<2, \d, 3>", 544, "ocml sincos stack"),
     (r"k_eval_kernel", 544, "ocml sincos stack"),
+    # one-launch prior level at three workgroups per CU (168 registers; two are slower: 26.1 vs 25.4 ms at config 5): row pointers
+    # and lane offsets of the epilogue are parked in scratch across the K loop (ISA: no scratch access inside the loop of 32 MFMAs)
+    (r"k_leaf_gemm<2, \d, [012], 2, 4, 256, 3, 1>", 64, "epilogue addresses parked across the K loop"),
     # dominant kernel at three workgroups per CU (168 registers): the staging registers of the NEXT level's operands are parked
     # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
     # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
