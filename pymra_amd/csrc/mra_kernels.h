@@ -53,6 +53,13 @@ __device__ __forceinline__ void gst4(double* p, d4 v) { *(d4 MRA_AS1*)p = v; }
 #define FT_SZ (16 * FT_LD)
 
 // row permutation of the "vec" tile layout (see k_trsm_rows2)
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, gfx950): lane l's piece lands at
+// lds_wave_base + 16 l - no staging registers, no ds_write.  lds_wave_base must be wave-uniform; completion is counted by vmcnt
+// (mra_wait_vm0() before the barrier that publishes the data).
+__device__ __forceinline__ void gld_lds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void mra_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int pi16(int rho) { return ((rho & 3) << 2) | (rho >> 2); }
 
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
@@ -2943,21 +2950,23 @@ struct PredArgs {
 #define MRA_PSTAMP_WALL(slot) do { } while (0)
 #endif
 
-// ---- staging of a level's operand tiles in TWO HALVES --------------------------------------------------------------------------
+// ---- staging of a level's operand tiles in TWO HALVES, straight into LDS ----------------------------------------------------
 // The LDS image of level m lists its tiles in the order the products consume them:
 //     slot 0 .. NTRI-1            strictly-lower tiles of Lt            (solve)
 //     slot NTRI .. NTRI+CWT-1     inverted diagonal blocks              (solve)
 //     then CWT tiles [jb] per front row block, ancestors first: k = 0 .. m-1, kt = 0 .. CWT-1  (front row block a = (m-1-k) CWT + kt,
 //     the level updates w[k][kt]), then the y row block (a = m CWT).
-// Half A = the solve tiles + the row blocks of the first kA = m / 2 ancestor levels, half B = the rest.  A thread holds only ONE half
-// in registers at a time (the loads of half B fly while the products of half A issue, those of the next level's half A during the
-// products of half B): 7 staging registers pairs at C3 instead of 13 - holding a whole level cost the predictive cascade 84 B / lane
-// of scratch at three workgroups per CU (0.4 GB of scratch write-back per launch).  Half A sits at the start of the LDS image,
-// half B at a fixed offset (the size of the deepest level's half A), so neither overwrites what the other half's products read.
-// Levels whose whole image fits the registers of one half are staged in one piece (kA = m, half B empty).
-template <int CWT> __device__ __forceinline__ constexpr int pred_tiles_a(int m, int ka) { return CWT * (CWT - 1) / 2 + CWT + ka * CWT * CWT; }
-template <int CWT> __device__ __forceinline__ constexpr int pred_tiles_all(int m) { return CWT * (CWT - 1) / 2 + CWT + (m * CWT + 1) * CWT; }
-template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int pred_half_regs() {
+// Half A = the solve tiles + the row blocks of the first kA = m / 2 ancestor levels, half B = the rest (never empty: the y row
+// block at least).  Half A lives at the start of the LDS image, half B at a fixed offset (the size of the deepest level's half A).
+// The pieces go from global memory straight into LDS (gld_lds16): half B of level m is requested when everybody has passed the
+// barrier that publishes half A (the region is free: level m+1's half-B products are done) and flies during the solve and the
+// half-A products; half A of level m-1 is requested behind the barrier that publishes half B and flies during the half-B products.
+// TWO barriers per level, no staging registers, no ds_write.  (Rounds 2-4 staged through registers: a whole level cost the
+// predictive cascade 84 B / lane of scratch at three workgroups per CU, half a level 7 register pairs and a third barrier.)
+template <int CWT> __host__ __device__ __forceinline__ constexpr int pred_tiles_a(int m, int ka) { return CWT * (CWT - 1) / 2 + CWT + ka * CWT * CWT; }
+template <int CWT> __host__ __device__ __forceinline__ constexpr int pred_tiles_all(int m) { return CWT * (CWT - 1) / 2 + CWT + (m * CWT + 1) * CWT; }
+// steps (of TPS tiles) of the largest half of any level
+template <int CWT, int NLMAX, int NTH> __host__ __device__ __forceinline__ constexpr int pred_half_steps() {
     int mx = 0;
     for (int m = 0; m < NLMAX; ++m) {
         const int ta = pred_tiles_a<CWT>(m, m / 2), tb = pred_tiles_all<CWT>(m) - ta;
@@ -2966,17 +2975,13 @@ template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int 
     }
     return (mx * 128 + NTH - 1) / NTH;
 }
-// tiles of level m in half A: the solve tiles + the row blocks of m / 2 ancestor levels, or the whole level (y included, half B
-// empty) when it fits one half's registers
-template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int pred_sa(int m) {
-    return pred_tiles_all<CWT>(m) * 128 <= pred_half_regs<CWT, NLMAX, NTH>() * NTH ? pred_tiles_all<CWT>(m) : pred_tiles_a<CWT>(m, m / 2);
-}
-// issue the loads of LDS slots [S0, S0 + CNT) of level ms (operands of node chain[ms]) into pre[].  A tile is 128 pieces of 16
-// bytes, a wave moves half a tile per step, so WHICH tile a wave moves in step i is wave-uniform (tl = i TPS + wv): the tile
-// decoding runs on the scalar unit, without divergence, and the address is a scalar base plus ONE per-thread offset (row and
-// column of the piece inside its tile: thread constants; times the front's row stride for the tiles that come out of F) - with a
-// per-thread tile index the seven addresses of a range cost fourteen registers and a page of VALU code per range.
-#define MRA_PRED_ISSUE_RANGE(ms, lvl, S0, CNT) do { \
+// tiles of level m in half A
+template <int CWT> __host__ __device__ __forceinline__ constexpr int pred_sa(int m) { return pred_tiles_a<CWT>(m, m / 2); }
+// request LDS slots [S0, S0 + CNT) of level ms (operands of node chain[ms]) into the tiles T0 .. of the LDS image.  A tile is 128
+// pieces of 16 bytes, a wave moves half a tile per step, so WHICH tile a wave moves in step i is wave-uniform (tl = i TPS + wv): the
+// tile decoding runs on the scalar unit, and the global address is a scalar base plus ONE per-thread offset (row and column of the
+// piece inside its tile: thread constants; times the front's row stride for the tiles that come out of F).
+#define MRA_PRED_LOAD_RANGE(ms, lvl, S0, CNT, T0) do { \
                 const int ms_ = (ms); \
                 const PredLevel ls = (lvl); \
                 const int slot_s = chain[ms_]; \
@@ -2984,13 +2989,12 @@ template <int CWT, int NLMAX, int NTH> __device__ __forceinline__ constexpr int 
                 const double* invs = ls.invF + (long)slot_s * CWT * 256; \
                 const int cnt_ = (CNT), s0_ = (S0); \
                 const unsigned vz = (unsigned)(prow_c * ls.ld + pcol_c) * 8u, vi = (unsigned)(prow_c * 16 + pcol_c) * 8u; \
+                char* const lb_ = (char*)lds + (long)(T0) * 2048 + whalf * 1024; \
 _Pragma("unroll") \
                 for (int i = 0; i < PH; ++i) { \
-                    if (i * TPS < cnt_) { \
-                        /* straight-line scalar decode (selects, no branches: the loads of a range stay in one block and issue together); \
-                           a wave whose tile lies beyond the range re-reads the last one */ \
-                        const int tl = i * TPS + wv; \
-                        const int tile = s0_ + (tl < cnt_ ? tl : cnt_ - 1); \
+                    const int tl = i * TPS + wv; \
+                    if (i * TPS < cnt_ && tl < cnt_) { \
+                        const int tile = s0_ + tl; \
                         const bool is_tri = tile < NTRI, is_inv = !is_tri && tile < NTRI + CWT; \
                         int jbt = 1; \
 _Pragma("unroll") \
@@ -3002,17 +3006,8 @@ _Pragma("unroll") \
                         const int coloff = is_tri ? kbt * 16 : jbz * 16; \
                         const char* sbF = (const char*)(Fs + rowoff * ls.ld + coloff); \
                         const char* sbI = (const char*)(invs + (long)(is_inv ? tile - NTRI : 0) * 256); \
-                        pre[i] = *(const d2*)((is_inv ? sbI : sbF) + (is_inv ? vi : vz)); \
+                        gld_lds16((is_inv ? sbI : sbF) + (is_inv ? vi : vz), lb_ + (long)tl * 2048); \
                     } \
-                } \
-} while (0)
-// write the CNT tiles held in pre[] to LDS, starting at tile offset T0
-#define MRA_PRED_WRITE_RANGE(T0, CNT) do { \
-                const int cnt_ = (CNT); \
-                char* lb = (char*)lds + ((long)(T0) + wv) * 2048 + pidx_c * 16; \
-_Pragma("unroll") \
-                for (int i = 0; i < PH; ++i) { \
-                    if (i * TPS < cnt_ && i * TPS + wv < cnt_) *(d2*)(lb + i * TPS * 2048) = pre[i]; \
                 } \
 } while (0)
 template <int CWT, int NLMAX, int WPW, bool UPD, int MINB>
@@ -3021,14 +3016,14 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     constexpr int CW = CWT * 16;
     constexpr int NTRI = CWT * (CWT - 1) / 2;
     constexpr int NTH = 64 * WPW;
-    // staging registers: the 16-byte chunks of HALF a level's operand tiles this thread moves (see MRA_PRED_ISSUE_RANGE)
-    constexpr int PH = pred_half_regs<CWT, NLMAX, NTH>();
+    // staging steps of HALF a level's operand tiles (see MRA_PRED_LOAD_RANGE)
+    constexpr int PH = pred_half_steps<CWT, NLMAX, NTH>();
     constexpr int TPS = NTH / 128;                            // tiles the workgroup moves per staging step
-    d2 pre[PH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     // staging coordinates: this thread's piece of a tile (pidx_c of 128: row prow_c, first column pcol_c) and, wave-uniform,
-    // which of the TPS tiles of a step its wave works on
+    // which of the TPS tiles of a step its wave works on (wv) and which half of that tile (whalf: 64 pieces = 1 KB per wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7);
+    const int whalf = __builtin_amdgcn_readfirstlane(((int)threadIdx.x >> 6) & 1);
     const int pidx_c = (int)threadIdx.x & 127, prow_c = pidx_c >> 3, pcol_c = (pidx_c & 7) << 1;
     const long t0 = ar.wg_tile0[blockIdx.x];
     const int nt_wg = ar.wg_ntiles[blockIdx.x];
@@ -3057,12 +3052,11 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     MRA_PSTAMP(0);
     MRA_PSTAMP_WALL(13);
     bool pre_issued = false;
-    // tile offset of half B in the LDS image: the size of the deepest level's half A (no shallower level's half A is larger
-    // unless it is staged in one piece, and then nothing of a half B is alive any more)
-    const int offb = pred_sa<CWT, NLMAX, NTH>(ar.nl - 1);
+    // tile offset of half B in the LDS image: the size of the deepest level's half A (no shallower level's half A is larger)
+    const int offb = pred_sa<CWT>(ar.nl - 1);
 // half A of the deepest level (a run-time level number: ar.deep = ar.lev[ar.nl - 1], a run-time index into lev[] would put the
 // whole argument block in scratch)
-#define MRA_PRED_ISSUE_DEEP_A() MRA_PRED_ISSUE_RANGE(ar.nl - 1, ar.deep, 0, offb)
+#define MRA_PRED_LOAD_DEEP_A() MRA_PRED_LOAD_RANGE(ar.nl - 1, ar.deep, 0, offb, 0)
     if (UPD) {
         const int lf = ar.wg_leaf[blockIdx.x];              // all tiles of a workgroup belong to one leaf
         const int nc = ar.leaf_upd[lf] ? (ar.leaf_nop[lf] >> 3) : 0;      // chunks of 8 k
@@ -3076,26 +3070,25 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
             const int nat = ar.nl * CWT + 1;
             const int nch = nat * 64;                        // 16-byte pieces of a (nat*16) x 8 chunk of Ut, 4 per row
             constexpr int NSTU = ((NLMAX * CWT + 1) * 64 + NTH - 1) / NTH;
-            double* cur = lds;
-            double* nxt = lds + (long)nat * 128;
-            // Ut chunk staging: step g moves rows g NTH/4 .. of the chunk (4 pieces per row): a scalar base per step plus ONE
-            // per-thread offset (four 64-bit pointers before); threads beyond the chunk's last row re-read their step's first row
-            d2 sg[NSTU];
+            // the two Ut chunk buffers sit in the half-B region of the LDS image: the deepest level's half A is requested into its
+            // own region while the last chunk's products issue
+            double* cur = lds + (long)offb * 256;
+            double* nxt = cur + (long)nat * 128;
+            // Ut chunk staging, straight into LDS: step g moves rows g NTH/4 .. of the chunk (4 pieces per row, piece e = thread + g NTH
+            // lands at byte 16 e): a scalar base per step plus ONE per-thread offset; nch is a multiple of 64, so a wave is in or out
             const unsigned uvo = (unsigned)(((int)threadIdx.x >> 2) * (int)nop + (((int)threadIdx.x & 3) << 1)) * 8u;
-#define MRA_PRED_UT_LOADS(kcol) do { \
+#define MRA_PRED_UT_LOADS(kcol, DST) do { \
 _Pragma("unroll") \
                 for (int g = 0; g < NSTU; ++g) { \
-                    if (g * NTH < nch) { \
+                    if (g * NTH + wave * 64 < nch) { \
                         const char* ub = (const char*)(ut + (long)(g * (NTH / 4)) * nop + (kcol)); \
-                        const unsigned vo = ((g + 1) * NTH <= nch || (int)threadIdx.x + g * NTH < nch) ? uvo : (unsigned)(((int)threadIdx.x & 3) << 4); \
-                        sg[g] = *(const d2*)(ub + vo); \
+                        gld_lds16(ub + uvo, (char*)(DST) + (long)(g * NTH + wave * 64) * 16); \
                     } \
                 } \
 } while (0)
-            MRA_PRED_UT_LOADS(0);
+            MRA_PRED_UT_LOADS(0, cur);
             d2 xc = *(const d2*)tt;
-#pragma unroll
-            for (int g = 0; g < NSTU; ++g) { const int e = (int)threadIdx.x + g * NTH; if (e < nch) *(d2*)(cur + 2 * e) = sg[g]; }
+            mra_wait_vm0();
             __syncthreads();
             MRA_PSTAMP(1);
 // one 8-k chunk: the Ut fragments of level k+1 are read while the products of level k issue, and no further ahead (left
@@ -3129,18 +3122,16 @@ _Pragma("unroll") \
 #pragma nounroll
             for (int c = 0; c + 1 < nc; ++c) {
                 const int kn = (c + 1) * 8;
-                MRA_PRED_UT_LOADS(kn);
+                MRA_PRED_UT_LOADS(kn, nxt);                   // (nxt was read two chunks ago: everybody has passed a barrier since)
                 const d2 xn = *(const d2*)(tt + kn);
                 MRA_PRED_UPD_CHUNK();
-#pragma unroll
-                for (int g = 0; g < NSTU; ++g) { const int e = (int)threadIdx.x + g * NTH; if (e < nch) *(d2*)(nxt + 2 * e) = sg[g]; }
+                mra_wait_vm0();
                 __syncthreads();
                 xc = xn;
                 double* const sw = cur; cur = nxt; nxt = sw;
             }
-            // the deepest level's operands ride behind the last chunk (issued inside the loop, their address arithmetic
-            // is hoisted out of it and spills)
-            MRA_PRED_ISSUE_DEEP_A();
+            // the deepest level's half A rides behind the last chunk, into its own region of the image
+            MRA_PRED_LOAD_DEEP_A();
             pre_issued = true;
             MRA_PRED_UPD_CHUNK();
         }
@@ -3150,17 +3141,14 @@ _Pragma("unroll") \
     for (int mm = 0; mm < NLMAX; ++mm) {
         const int m = NLMAX - 1 - mm;
         if (m < ar.nl) {
-            const int SA = pred_sa<CWT, NLMAX, NTH>(m);      // tiles in half A; half B: the remaining TB tiles at tile offset offb
+            const int SA = pred_sa<CWT>(m);                   // tiles in half A; half B: the remaining TB tiles at tile offset offb
             const int TB = pred_tiles_all<CWT>(m) - SA;
-            // ---- stage: all of a thread's loads of a half are issued together, and always BEFORE the products of the half in
-            // front of it, so their L2 round trip (a load -> ds_write loop pays ~1 us per chunk, which was half of this kernel's
-            // run time) hides behind MFMA work.
-            if (m == ar.nl - 1 && !pre_issued) MRA_PRED_ISSUE_RANGE(m, ar.lev[m], 0, SA);   // the first (deepest) level of this tree
-            __syncthreads();                                  // everybody is done with the previous level's LDS image (both halves)
-            MRA_PRED_WRITE_RANGE(0, SA);
-            if (TB > 0) MRA_PRED_ISSUE_RANGE(m, ar.lev[m], SA, TB);
-            else if (m > 0) MRA_PRED_ISSUE_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT, NLMAX, NTH>(m - 1)));
-            __syncthreads();
+            // ---- stage: a half is requested (global -> LDS, no registers) BEFORE the products of the half in front of it, so its L2
+            // round trip (a load -> ds_write loop pays ~1 us per chunk, which was half of this kernel's run time) hides behind MFMA work
+            if (m == ar.nl - 1 && !pre_issued) MRA_PRED_LOAD_RANGE(m, ar.lev[m], 0, SA, 0);   // the first (deepest) level of this tree, no leaf update in front of it: LDS is untouched
+            mra_wait_vm0();
+            __syncthreads();                                  // half A has landed, and everybody is done with the previous level's half B
+            MRA_PRED_LOAD_RANGE(m, ar.lev[m], SA, TB, offb);
             if (m < 5) MRA_PSTAMP(3 + 2 * m);
             d4 x[CWT];                                        // MINUS X_m: every product below accumulates straight into its w tile (no separate accumulator: 8 registers)
             // tile slot -> LDS address (slots below SA in half A, the others in half B)
@@ -3190,10 +3178,9 @@ _Pragma("unroll") \
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (half == 1) {
-                    if (TB == 0) break;
-                    MRA_PRED_WRITE_RANGE(offb, TB);
-                    if (m > 0) MRA_PRED_ISSUE_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT, NLMAX, NTH>(m - 1)));
-                    __syncthreads();
+                    mra_wait_vm0();
+                    __syncthreads();                          // half B has landed, and everybody is done with half A
+                    if (m > 0) MRA_PRED_LOAD_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT>(m - 1)), 0);
                 }
                 if (active) {
 #pragma unroll

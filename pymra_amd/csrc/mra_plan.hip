@@ -1323,7 +1323,8 @@ static void run_predict_fused(mra_plan* pl) {
         // the leaf update rides in this launch (two Ut chunk stages share the LDS with the level operands)
         ar.tile_leaf = pl->ft_leaf.p; ar.wg_leaf = pl->ft_wgleaf_x.p; ar.leaf_ut = pl->leaf_ut.p; ar.leaf_nop = pl->leaf_nop_dev.p; ar.leaf_row0 = pl->leaf_row0_dev.p;
         ar.leaf_upd = pl->leaf_upd_dev.p; ar.na = pl->na[pl->NL];
-        lds = std::max(lds, (size_t)(2 * (pl->NL * cwt + 1) * 128) * sizeof(double));      // two 8-k chunks of Ut
+        // two 8-k chunks of Ut behind the deepest level's half A (which is requested while the last chunk's products issue)
+        lds = std::max(lds, (size_t)(cwt * (cwt - 1) / 2 + cwt + (mmax / 2) * cwt * cwt) * 2048 + (size_t)(2 * (pl->NL * cwt + 1) * 128) * sizeof(double));
         fl += Work(pl->fl_leaf_update.alg, pl->fl_leaf_update.exec, pl->by_leaf_tt + pl->by_leaf_ut);    // Tt and Ut in, nothing out
     }
 #ifdef MRA_STAMPS

@@ -733,6 +733,15 @@ def test_random_geometries(hip, seed):
     pl.run(True, False)
     d, u = pl.likelihood()
     assert abs(d + u - lik) <= 1e-11 * max(1.0, abs(lik))
+    # the level-by-level kernels on the same plan: the prior of a level in one launch (option 15, the default there) and as
+    # residual product + gather + factorisation + row solve
+    for one_launch in (1, 0):
+        pl.set_option(2, 0); pl.set_option(15, one_launch)
+        pl.run(True, True)
+        d, u = pl.likelihood()
+        m2, v2 = pl.predict()
+        assert abs(d + u - lik) <= 1e-10 * max(1.0, abs(lik)), one_launch
+        assert np.max(np.abs(m2 - mean)) < 1e-9 and np.max(np.abs(np.sqrt(np.maximum(v2, 0)) - np.sqrt(np.maximum(var, 0)))) < 1e-8, one_launch
     pl.close()
 
 
