@@ -3256,21 +3256,32 @@ struct PredHiArgs {
     const int* tile_chain;
     const long* wg_tile0;     // per workgroup: first tile and number of tiles (<= 4), all sharing one chain
     const int* wg_ntiles;
+    // UPD: the leaf update W[S, anc | y] -= Tt Ut^T rides in this launch (leaves of at most 64 padded observations: four k tiles) -
+    // on the sixteen deep tiles in registers before the levels are walked, on every coarse tile as it passes through the sweep.
+    // The updated W never exists in memory: a read and a write of all of W less (36 GB at config 5).
+    const int* wg_leaf;       // [workgroup] leaf number of the workgroup's tiles (they share one)
+    double* const* leaf_ut;   // [leaf] solved Ut block (na x nop, rows: deepest level first, then coarser, then the y block), then the leaf's Tt rows
+    const int* leaf_nop;      // [leaf]
+    const long* leaf_row0;    // [leaf] first padded row
+    int na;                   // rows of Ut
 };
 
-// the 16-byte pieces of a 16-tile chunk this thread stages: piece i is row (chunk >> 3), doubles c2, c2+1 of tile tsel + 2 i
-#define MRA_PH_ISSUE_Z(F0, N0, A0, F1, N1, A1, F2, N2, A2, F3, N3, A3) do { \
-        pre[0] = gld2((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + sjb0 * 16 + sc2); \
-        pre[1] = gld2((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + (sjb0 + 2) * 16 + sc2); \
-        pre[2] = gld2((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + sjb0 * 16 + sc2); \
-        pre[3] = gld2((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + (sjb0 + 2) * 16 + sc2); \
-        pre[4] = gld2((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + sjb0 * 16 + sc2); \
-        pre[5] = gld2((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + (sjb0 + 2) * 16 + sc2); \
-        pre[6] = gld2((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + sjb0 * 16 + sc2); \
-        pre[7] = gld2((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + (sjb0 + 2) * 16 + sc2); \
+// the 16-byte pieces of a 16-tile chunk this thread moves: piece i is row (chunk >> 3), doubles c2, c2+1 of tile tsel + 2 i; they go
+// from global memory straight into the LDS buffer DST (gld_lds16: lane-linear, a wave fills half a tile = 1 KB per instruction)
+#define MRA_PH_LOAD_Z(DST, F0, N0, A0, F1, N1, A1, F2, N2, A2, F3, N3, A3) do { \
+        char* const db_ = (char*)(DST) + (long)stile0 * 2048 + whalf * 1024; \
+        gld_lds16((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + sjb0 * 16 + sc2, db_ + 0 * 4096); \
+        gld_lds16((F0) + (long)(64 + (A0) * 16 + srow) * (N0) + (sjb0 + 2) * 16 + sc2, db_ + 1 * 4096); \
+        gld_lds16((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + sjb0 * 16 + sc2, db_ + 2 * 4096); \
+        gld_lds16((F1) + (long)(64 + (A1) * 16 + srow) * (N1) + (sjb0 + 2) * 16 + sc2, db_ + 3 * 4096); \
+        gld_lds16((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + sjb0 * 16 + sc2, db_ + 4 * 4096); \
+        gld_lds16((F2) + (long)(64 + (A2) * 16 + srow) * (N2) + (sjb0 + 2) * 16 + sc2, db_ + 5 * 4096); \
+        gld_lds16((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + sjb0 * 16 + sc2, db_ + 6 * 4096); \
+        gld_lds16((F3) + (long)(64 + (A3) * 16 + srow) * (N3) + (sjb0 + 2) * 16 + sc2, db_ + 7 * 4096); \
 } while (0)
 // solve operands of hi level H: tiles 0..5 = strictly-lower tiles of Lt ((1,0) (2,0) (2,1) (3,0) (3,1) (3,2)), 6..9 = inverted diagonal blocks
-#define MRA_PH_ISSUE_T(H) do { \
+#define MRA_PH_LOAD_T(DST, H) do { \
+        char* const db_ = (char*)(DST) + (long)stile0 * 2048 + whalf * 1024; \
 _Pragma("unroll") \
         for (int i = 0; i < 5; ++i) { \
             const int tile = stile0 + 2 * i; \
@@ -3279,20 +3290,34 @@ _Pragma("unroll") \
                 const int jb = tile < 1 ? 1 : (tile < 3 ? 2 : 3), kb = tile - jb * (jb - 1) / 2; \
                 src = Fh[H] + (long)(jb * 16 + srow) * nfh[H] + kb * 16 + sc2; \
             } else src = invh[H] + (long)(tile - 6) * 256 + srow * 16 + sc2; \
-            pre[i] = gld2(src); \
+            gld_lds16(src, db_ + i * 4096); \
         } \
 } while (0)
-#define MRA_PH_WRITE(BUF, NPIECE) do { \
+// the requested chunk has landed and everybody is done with the buffer the next request overwrites
+#define MRA_PH_SYNC() do { mra_wait_vm0(); __syncthreads(); } while (0)
+// leaf update, deep part: k tile KT of the Ut rows of the sixteen deep tiles (Ut row tile a = (3 - h) 4 + jb: the deepest level first)
+#define MRA_PH_LOAD_UT0(DST, KT) do { \
+        char* const db_ = (char*)(DST) + (long)stile0 * 2048 + whalf * 1024; \
 _Pragma("unroll") \
-        for (int i = 0; i < (NPIECE); ++i) *(d2*)((BUF) + (long)(stile0 + 2 * i) * 256 + srow * 16 + sc2) = pre[i]; \
+        for (int i = 0; i < 8; ++i) gld_lds16(ut + (long)((stile0 + 2 * i) * 16 + srow) * nop + (KT) * 16 + sc2, db_ + i * 4096); \
+} while (0)
+// leaf update, sweep part: the (at most four) k tiles of the Ut rows of coarse tile I, behind the sixteen Zt tiles of the chunk
+#define MRA_PH_LOAD_UTV(DST, I) do { \
+        if (UPD) { \
+_Pragma("unroll") \
+            for (int i2 = 0; i2 < 2; ++i2) \
+                if (stile0 + 2 * i2 < nkt) \
+                    gld_lds16(ut + (long)((16 + (I)) * 16 + srow) * nop + (stile0 + 2 * i2) * 16 + sc2, (char*)(DST) + (long)(16 + stile0 + 2 * i2) * 2048 + whalf * 1024); \
+        } \
 } while (0)
 
-template <int CWT>        // = 4 (a template so that only the translation unit that launches it instantiates it)
+template <int CWT, bool UPD>        // CWT = 4 (a template so that only the translation unit that launches it instantiates it)
 __global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
     static_assert(CWT == 4, "k_predict_hi is written for 64-wide blocks");
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int CHT = UPD ? 20 : 16;                     // tiles per chunk buffer: sixteen operand tiles (+ up to four k tiles of Ut in the sweep)
     double* const buf0 = lds;
-    double* const buf1 = lds + 16 * 256;
+    double* const buf1 = lds + CHT * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     const long t0 = ar.wg_tile0[blockIdx.x];
     const int nt_wg = ar.wg_ntiles[blockIdx.x];
@@ -3305,7 +3330,8 @@ __global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
     const int* chain = ar.tile_chain + t0 * 8 + ar.lev0;
     double* const wrow = ar.W + myrow * ar.ldw + 4 * q;
     // staging role of this thread inside a 16-tile chunk
-    const int stile0 = threadIdx.x >> 7, sjb0 = stile0, schunk = threadIdx.x & 127, srow = schunk >> 3, sc2 = (schunk & 7) << 1;
+    const int stile0 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 7), sjb0 = stile0, schunk = threadIdx.x & 127, srow = schunk >> 3, sc2 = (schunk & 7) << 1;
+    const int whalf = __builtin_amdgcn_readfirstlane(((int)threadIdx.x >> 6) & 1);
     const double* Fh[4];
     const double* invh[4];
     long nfh[4];
@@ -3316,7 +3342,6 @@ __global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
         Fh[h] = ar.hi[h].F + slot * ar.hi[h].stride;
         invh[h] = ar.hi[h].invF + slot * 4 * 256;
     }
-    d2 pre[8];
     d4 w[4][4];
 #pragma unroll
     for (int h = 0; h < 4; ++h)
@@ -3324,10 +3349,57 @@ __global__ __launch_bounds__(256, 2) void k_predict_hi(PredHiArgs ar) {
         for (int jb = 0; jb < 4; ++jb) w[h][jb] = *(const d4*)(wrow + ar.coff_hi[h] + jb * 16);
     double ssq = 0.0;
     const int fo = prow * 16 + 4 * q;                      // this lane's fragment inside a staged tile
-    // ---- the four deepest levels, deepest first; chunk c lives in buffer c & 1
-    MRA_PH_ISSUE_T(3);
-    MRA_PH_WRITE(buf0, 5);
-    __syncthreads();
+    // ---- leaf update of the sixteen deep tiles: w[h][jb] -= Tt Ut[(3 - h) 4 + jb]^T, one chunk of sixteen Ut tiles per k tile
+    int nkt = 0;
+    long nop = 0;
+    const double* ut = nullptr;
+    const double* ttp = nullptr;                           // this lane's share of the row tile's Tt rows (vec layout: row r, k = 4 q ..)
+    if (UPD) {
+        const int lf = ar.wg_leaf[blockIdx.x];
+        nop = ar.leaf_nop[lf];
+        nkt = __builtin_amdgcn_readfirstlane((int)(nop >> 4));
+        ut = ar.leaf_ut[lf];
+        ttp = ut + (long)ar.na * nop + (myrow - ar.leaf_row0[lf]) * nop + 4 * q;
+    }
+#define MRA_PH_UPD0(TT, BUF) do { \
+        if (active) { \
+_Pragma("unroll") \
+            for (int h = 0; h < 4; ++h) { \
+_Pragma("unroll") \
+                for (int jb = 0; jb < 4; ++jb) { \
+                    const d4 z = *(const d4*)((BUF) + ((3 - h) * 4 + jb) * 256 + fo); \
+_Pragma("unroll") \
+                    for (int j = 0; j < 4; ++j) w[h][jb] = mfma16(z[j], (TT)[j], w[h][jb]); \
+                } \
+                __builtin_amdgcn_sched_barrier(0);   /* four fragment reads in flight, not sixteen (128 registers) */ \
+            } \
+        } \
+} while (0)
+    // ---- the four deepest levels, deepest first; the solve operands of the deepest level end up in buf0 whatever came before: k
+    // tile kt of the leaf update sits in buf1 when nkt - 1 - kt is even (the last one always), in buf0 otherwise
+    d4 tt[4] = {zero, zero, zero, zero};                   // MINUS Tt, k tiles 0 .. 3, for the sweep (loaded behind the deep part: sixteen w tiles + these is the register peak)
+    if (UPD && nkt > 0) {
+        double* bc = ((nkt - 1) & 1) ? buf0 : buf1;
+        double* bn = ((nkt - 1) & 1) ? buf1 : buf0;
+        MRA_PH_LOAD_UT0(bc, 0);
+        d4 tk = -*(const d4*)ttp;
+        MRA_PH_SYNC();
+#pragma nounroll
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
+            MRA_PH_LOAD_UT0(bn, kt + 1);
+            const d4 tn = -*(const d4*)(ttp + (kt + 1) * 16);
+            MRA_PH_UPD0(tk, bc);
+            MRA_PH_SYNC();
+            tk = tn;
+            double* const sw = bc; bc = bn; bn = sw;
+        }
+        MRA_PH_LOAD_T(buf0, 3);    MRA_PH_UPD0(tk, buf1);  MRA_PH_SYNC();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) if (kt < nkt) tt[kt] = -*(const d4*)(ttp + kt * 16);
+    } else {
+        MRA_PH_LOAD_T(buf0, 3);
+        MRA_PH_SYNC();
+    }
 #define MRA_PH_SOLVE(H, BUF) do { \
         if (active) { \
             d4 x[4]; \
@@ -3371,39 +3443,57 @@ _Pragma("unroll") \
             } \
         } \
 } while (0)
-#define MRA_PH_ISSUE_U(H, HP) MRA_PH_ISSUE_Z(Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 0, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 1, \
-                                             Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 2, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 3)
-    // level 3 (deepest)
-    MRA_PH_ISSUE_U(3, 2);  MRA_PH_SOLVE(3, buf0);      MRA_PH_WRITE(buf1, 8); __syncthreads();
-    MRA_PH_ISSUE_U(3, 1);  MRA_PH_UPDATE(3, 2, buf1);  MRA_PH_WRITE(buf0, 8); __syncthreads();
-    MRA_PH_ISSUE_U(3, 0);  MRA_PH_UPDATE(3, 1, buf0);  MRA_PH_WRITE(buf1, 8); __syncthreads();
-    MRA_PH_ISSUE_T(2);     MRA_PH_UPDATE(3, 0, buf1);  MRA_PH_WRITE(buf0, 5); __syncthreads();
+#define MRA_PH_LOAD_U(DST, H, HP) MRA_PH_LOAD_Z(DST, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 0, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 1, \
+                                                Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 2, Fh[H], nfh[H], ((H) - 1 - (HP)) * 4 + 3)
+    // level 3 (deepest): the operands of the step behind are requested into the other buffer, the products of this step issue,
+    // then wait + barrier
+    MRA_PH_LOAD_U(buf1, 3, 2);  MRA_PH_SOLVE(3, buf0);      MRA_PH_SYNC();
+    MRA_PH_LOAD_U(buf0, 3, 1);  MRA_PH_UPDATE(3, 2, buf1);  MRA_PH_SYNC();
+    MRA_PH_LOAD_U(buf1, 3, 0);  MRA_PH_UPDATE(3, 1, buf0);  MRA_PH_SYNC();
+    MRA_PH_LOAD_T(buf0, 2);     MRA_PH_UPDATE(3, 0, buf1);  MRA_PH_SYNC();
     // level 2
-    MRA_PH_ISSUE_U(2, 1);  MRA_PH_SOLVE(2, buf0);      MRA_PH_WRITE(buf1, 8); __syncthreads();
-    MRA_PH_ISSUE_U(2, 0);  MRA_PH_UPDATE(2, 1, buf1);  MRA_PH_WRITE(buf0, 8); __syncthreads();
-    MRA_PH_ISSUE_T(1);     MRA_PH_UPDATE(2, 0, buf0);  MRA_PH_WRITE(buf1, 5); __syncthreads();
+    MRA_PH_LOAD_U(buf1, 2, 1);  MRA_PH_SOLVE(2, buf0);      MRA_PH_SYNC();
+    MRA_PH_LOAD_U(buf0, 2, 0);  MRA_PH_UPDATE(2, 1, buf1);  MRA_PH_SYNC();
+    MRA_PH_LOAD_T(buf1, 1);     MRA_PH_UPDATE(2, 0, buf0);  MRA_PH_SYNC();
     // level 1
-    MRA_PH_ISSUE_U(1, 0);  MRA_PH_SOLVE(1, buf1);      MRA_PH_WRITE(buf0, 8); __syncthreads();
-    MRA_PH_ISSUE_T(0);     MRA_PH_UPDATE(1, 0, buf0);  MRA_PH_WRITE(buf1, 5); __syncthreads();
+    MRA_PH_LOAD_U(buf0, 1, 0);  MRA_PH_SOLVE(1, buf1);      MRA_PH_SYNC();
+    MRA_PH_LOAD_T(buf1, 0);     MRA_PH_UPDATE(1, 0, buf0);  MRA_PH_SYNC();
     // level 0 of the four; behind it the first coarse tile's operands
     const int n_low = ar.n_low;
     double* const wlow = wrow + ar.col_low;
-#define MRA_PH_ISSUE_V(I) MRA_PH_ISSUE_Z(Fh[0], nfh[0], 0 + (I), Fh[1], nfh[1], 4 + (I), Fh[2], nfh[2], 8 + (I), Fh[3], nfh[3], 12 + (I))
-    MRA_PH_ISSUE_V(0);
+#define MRA_PH_LOAD_V(DST, I) MRA_PH_LOAD_Z(DST, Fh[0], nfh[0], 0 + (I), Fh[1], nfh[1], 4 + (I), Fh[2], nfh[2], 8 + (I), Fh[3], nfh[3], 12 + (I))
+    MRA_PH_LOAD_V(buf0, 0);
+    MRA_PH_LOAD_UTV(buf0, 0);
     d4 wl = *(const d4*)wlow;
     MRA_PH_SOLVE(0, buf1);
-    MRA_PH_WRITE(buf0, 8);
-    __syncthreads();
+    MRA_PH_SYNC();
     // ---- one sweep over the coarse tiles: w_i -= sum_h X_h Zt_h[4 h + i]^T  (tile (h, jb) of the chunk)
 #pragma nounroll
     for (int i = 0; i < n_low; ++i) {
         const double* bufc = (i & 1) ? buf1 : buf0;
         double* bufn = (i & 1) ? buf0 : buf1;
         const int in = (i + 1 < n_low) ? i + 1 : i;
-        MRA_PH_ISSUE_V(in);
+        if (i + 1 < n_low) { MRA_PH_LOAD_V(bufn, in); MRA_PH_LOAD_UTV(bufn, in); }
         const d4 wn = *(const d4*)(wlow + in * 16);
+        if (UPD && i == n_low - 1) wl = zero;              // the y block takes C_in = 0 in the leaf update (the column still holds y itself)
         if (active) {
             d4 acc0 = zero, acc1 = zero;
+            if (UPD) {
+                // leaf update of this coarse tile: + Tt Ut[16 + i]^T with tt = -Tt, i.e. subtracted from the sum that is subtracted below
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    if (kt < nkt) {
+                        const d4 z = *(const d4*)(bufc + (16 + kt) * 256 + fo);
+                        if (kt & 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc1 = mfma16(z[j], tt[kt][j], acc1);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc0 = mfma16(z[j], tt[kt][j], acc0);
+                        }
+                    }
+                acc0 = -acc0; acc1 = -acc1;
+            }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
 #pragma unroll
@@ -3421,8 +3511,7 @@ _Pragma("unroll") \
             *(d4*)(wlow + i * 16) = wl - (acc0 + acc1);
         }
         wl = wn;
-        if (i + 1 < n_low) MRA_PH_WRITE(bufn, 8);
-        __syncthreads();
+        MRA_PH_SYNC();
     }
     if (!active) return;
     ssq += __shfl_xor(ssq, 16, 64);

@@ -31,9 +31,12 @@ void launch_predict_any(mra_plan* pl, const PredArgs& ar, size_t lds) {
 
 // deep 64-wide trees: the four deepest levels + the sweep over the coarse columns, then the (at most four) coarse levels with
 // eight row tiles per workgroup (k_predict_cascade<4, 4, 8, false, 1>: 236 registers, no scratch)
-void launch_predict_hi(mra_plan* pl, const PredHiArgs& hi, const PredArgs& low, size_t lds_low) {
-    ensure_big_lds(pl, {(const void*)k_predict_hi<4>, (const void*)k_predict_cascade<4, 4, 8, false, 1>});
+void launch_predict_hi(mra_plan* pl, const PredHiArgs& hi, const PredArgs& low, size_t lds_low, bool upd) {
+    ensure_big_lds(pl, {(const void*)k_predict_hi<4, false>, (const void*)k_predict_hi<4, true>, (const void*)k_predict_cascade<4, 4, 8, false, 1>});
     if (pl->prepare_only) return;
-    hipLaunchKernelGGL(k_predict_hi<4>, dim3((unsigned)pl->n_fwg), dim3(256), 2 * 16 * 256 * sizeof(double), pl->stream, hi);
+    // two chunk buffers of sixteen tiles (twenty with the leaf update: up to four k tiles of Ut ride behind the Zt tiles of the sweep:
+    // 2 x 80 KB = all of a CU's LDS for two workgroups)
+    if (upd) hipLaunchKernelGGL((k_predict_hi<4, true>), dim3((unsigned)pl->n_fwg), dim3(256), 2 * 20 * 256 * sizeof(double), pl->stream, hi);
+    else hipLaunchKernelGGL((k_predict_hi<4, false>), dim3((unsigned)pl->n_fwg), dim3(256), 2 * 16 * 256 * sizeof(double), pl->stream, hi);
     hipLaunchKernelGGL((k_predict_cascade<4, 4, 8, false, 1>), dim3((unsigned)low.n_wg), dim3(512), lds_low, pl->stream, low);
 }

@@ -476,7 +476,7 @@ static void build_static(mra_plan* pl) {
             // row tiles of the leaves with their ancestor chains; one workgroup per leaf (<= 4 tiles) for k_predict_hi, groups of eight
             // consecutive tiles below one level-(NL-5) node for the coarse cascade
             std::vector<long> r0s, wg0, wg0_8;
-            std::vector<int> chains, wgn, wgn_8;
+            std::vector<int> chains, wgn, wgn_8, wgl;
             const int nlo = NL - 4;
             int prev_coarse = -1;
             for (size_t t = 0; t < pl->leaf_nodes.size(); ++t) {
@@ -486,7 +486,7 @@ static void build_static(mra_plan* pl) {
                 const int coarse = ch[nlo - 1];                          // slot of the deepest coarse level: same slot = same coarse chain
                 for (long p = pl->row0[i]; p < pl->row1[i]; p += 16) {
                     const long k = (p - pl->row0[i]) / 16;
-                    if (k % 4 == 0) { wg0.push_back((long)r0s.size()); wgn.push_back((int)std::min<long>(4, (pl->row1[i] - p) / 16)); }
+                    if (k % 4 == 0) { wg0.push_back((long)r0s.size()); wgn.push_back((int)std::min<long>(4, (pl->row1[i] - p) / 16)); wgl.push_back((int)t); }
                     if (wgn_8.empty() || wgn_8.back() == 8 || coarse != prev_coarse) { wg0_8.push_back((long)r0s.size()); wgn_8.push_back(0); }
                     ++wgn_8.back();
                     prev_coarse = coarse;
@@ -497,6 +497,7 @@ static void build_static(mra_plan* pl) {
             pl->ft_row0.upload(r0s); pl->ft_chain.upload(chains);
             pl->n_ftiles = (long)r0s.size();
             pl->ft_wg0.upload(wg0); pl->ft_wgn.upload(wgn); pl->n_fwg = (long)wg0.size();
+            pl->hi_wgleaf.upload(wgl);
             pl->hi_wg0_8.upload(wg0_8); pl->hi_wgn_8.upload(wgn_8); pl->n_hi_wg8 = (long)wg0_8.size();
         }
     }
@@ -1285,6 +1286,11 @@ static void run_predict_hi(mra_plan* pl) {
     hi.tile_row0 = pl->ft_row0.p; hi.tile_chain = pl->ft_chain.p; hi.wg_tile0 = pl->ft_wg0.p; hi.wg_ntiles = pl->ft_wgn.p;
     // W read once, its coarse columns and y block written once; var in and out
     fl_hi.bytes = 8.0 * pl->P * (pl->ldw + (pl->ldw - pl->coff[nlo - 1]) + 2);
+    if (pl->hi_fold_now) {
+        // the leaf update rides in k_predict_hi (Tt and Ut in, nothing out)
+        hi.wg_leaf = pl->hi_wgleaf.p; hi.leaf_ut = pl->leaf_ut.p; hi.leaf_nop = pl->leaf_nop_dev.p; hi.leaf_row0 = pl->leaf_row0_dev.p; hi.na = pl->na[NL];
+        fl_hi += Work(pl->fl_leaf_update.alg, pl->fl_leaf_update.exec, pl->by_leaf_tt + pl->by_leaf_ut);
+    }
     PredArgs lo{};
     for (int m = 0; m < nlo; ++m) {
         lo.lev[m].F = pl->lev[m].F.p; lo.lev[m].invF = pl->lev[m].invF.p; lo.lev[m].nf = pl->lev[m].nf;
@@ -1300,7 +1306,7 @@ static void run_predict_hi(mra_plan* pl) {
     const size_t lds_low = (size_t)(4 * 3 / 2 + 4 + ((nlo - 1) * 4 + 1) * 4) * 2048;
     // two launches; the kernel timer brackets both (the coarse share is reported with them: they are one pass over W's coarse half)
     KTimer kt(pl, KF_PRED_UPDATE, fl_hi + fl_lo);
-    launch_predict_hi(pl, hi, lo, lds_low);
+    launch_predict_hi(pl, hi, lo, lds_low, pl->hi_fold_now);
 }
 
 static void run_predict_fused(mra_plan* pl) {
@@ -1594,6 +1600,7 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     pl->side_pending = false;
     pl->split_pending = false;
     pl->pred_update_now = false;
+    pl->hi_fold_now = false;
     pl->pass_open = true;
     pl->run_flags = flags;
     for (int k = 0; k < KF_COUNT; ++k) pl->kstat[k] = mra_plan::KStat();
@@ -1774,7 +1781,14 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             }
             pl->pred_update_now = !solve_fused && fused && pl->use_pred_update && pl->leaf_solve_ok && pl->leaf_max_nop / 16 <= 12 &&
                                   pl->na[pl->NL] == (pl->NL * pl->CWT + 1) * 16;
-            if (pl->pred_update_now) {
+            // deep 64-wide trees: the update rides in k_predict_hi (leaves of at most four observation tiles, 16 x 16-padded ancestors + y)
+            // (a sharded rank keeps the separate product: it runs on the side stream beside the front chain and the all-reduce, whereas
+            // k_predict_hi sits behind them on the rank's critical path; option 16 = 2 folds there too, for A/B runs)
+            pl->hi_fold_now = !solve_fused && !fused && pl->use_hi_fold && (pl->reduce_level < 0 || pl->use_hi_fold == 2) && pl->regular_hi && pl->use_fused &&
+                              !pl->host_cov && pl->leaf_max_nop <= 64 && pl->na[pl->NL] == (pl->NL * 4 + 1) * 16;
+            if (pl->hi_fold_now) {
+                // nothing to launch here
+            } else if (pl->pred_update_now) {
                 // the small leaves (<= 8 observation tiles) take their update inside the predictive cascade; the few larger ones here
                 const size_t ns = pl->n_trsm_small;
                 if (nl > ns) {
@@ -2297,6 +2311,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 12) { pl->seg_gemm_lds = value != 0; return MRA_OK; }
     if (option == 14) { pl->use_syrk_blk = value != 0; return MRA_OK; }
     if (option == 15) { pl->use_prior_level = value != 0; return MRA_OK; }
+    if (option == 16) { pl->use_hi_fold = (int)value; return MRA_OK; }
     if (option == 13) { pl->ut_gather = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
@@ -2329,6 +2344,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 12: *value = pl->seg_gemm_lds; break;
         case 14: *value = pl->use_syrk_blk; break;
         case 15: *value = pl->use_prior_level; break;
+        case 16: *value = pl->use_hi_fold; break;
         case 13: *value = pl->ut_gather; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));

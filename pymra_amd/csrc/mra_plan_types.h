@@ -292,6 +292,8 @@ struct mra_plan {
     size_t n_chol_small = 0;
     bool ut_gather = true;                    // fused path: the leaves' Ut rows gathered from W by the row solve (no scatter in the row cascade: 1.21 -> 1.03 ms there, +0.16 ms in the solve)
     bool cphantom_valid = false;              // the phantom observation rows of the leaves' C blocks hold their identity rows
+    int use_hi_fold = 1;                      // deep 64-wide trees: the leaf update W -= Tt Ut^T inside k_predict_hi instead of a pass over all of W (option 16)
+    bool hi_fold_now = false;                 // ... decided for the pass that is running
     bool use_prior_level = true;              // levels of the level-by-level prior with blocks <= 64 wide: residual + kernel + row solve in one launch (option 15)
     bool parent_panel_lds_ok = false;         // every parent-panel problem fits the step table of the LDS-tiled segmented product
     bool grand_syrk_blk_ok = false;           // every grandparent problem fits k_syrk_blk's step table
@@ -339,6 +341,7 @@ struct mra_plan {
     bool var_accumulated = false;       // level-by-level path: the row solves have accumulated the prior / leaf variance (no k_leaf_moments pass)
     bool regular_hi = false;
     DevVec<long> hi_wg0_8;
+    DevVec<int> hi_wgleaf;                    // [k_predict_hi workgroup] leaf slot of its tiles
     DevVec<int> hi_wgn_8;
     long n_hi_wg8 = 0;
     bool regular = false, use_fused = true, gemm_lds = true, use_front_fused = true, use_leaf_gemm = true, leaf_gemm_update = false;
@@ -420,4 +423,4 @@ void launch_knot_chain_d2(mra_plan* pl, const KnotChainArgs& ka);
 static inline void launch_cascade_any(mra_plan* pl, const CascadeArgs& ar) { if (pl->d == 1) launch_cascade_d1(pl, ar); else launch_cascade_d2(pl, ar); }
 static inline void launch_knot_chain(mra_plan* pl, const KnotChainArgs& ka) { if (pl->d == 1) launch_knot_chain_d1(pl, ka); else launch_knot_chain_d2(pl, ka); }
 void launch_predict_any(mra_plan* pl, const PredArgs& ar, size_t lds);
-void launch_predict_hi(mra_plan* pl, const PredHiArgs& hi, const PredArgs& low, size_t lds_low);
+void launch_predict_hi(mra_plan* pl, const PredHiArgs& hi, const PredArgs& low, size_t lds_low, bool upd);

@@ -694,6 +694,47 @@ def test_plan_reuse_for_mle(hip):
     assert np.max(np.abs(np.asarray(base.predict()[0]).ravel() - cs["g"]["mean"])) < 1e-7
 
 
+@pytest.mark.parametrize("frac", [0.2, 0.6])
+def test_deep_wide_tree_leaf_update_inside_predict_hi(hip, frac):
+    """Deep 64-wide trees whose leaves have at most 64 padded observations (BASELINE config 5: 64 rows per leaf, up to four k tiles) take
+    the leaf update W[S, anc | y] -= Tt Ut^T inside k_predict_hi - on the sixteen deep tiles in registers, on every coarse tile as it
+    passes through the sweep - instead of as a pass over all of W.  Leaves with four, three, two, one and no observation tile, against the
+    separate product (option 16 = 0) and against the CPU oracle."""
+    import pymra_amd.MRATools as mt
+    from pymra_amd.topology import build_topology
+    from oracle.mra_levelwise import run_levelwise
+    n, r, M = 256, 64, 5
+    np.random.seed(29)
+    locs = mt.genLocations2d(Nx=n, Ny=n)
+    y = np.random.normal(size=(n * n, 1))
+    y_obs = np.where(np.random.uniform(size=(n * n, 1)) < frac, y, np.nan)
+    topo = build_topology(locs, r, M, 4)
+    leaves = [i for i in range(topo.n_nodes) if topo.node_leaf[i]]
+    for i in (leaves[0], leaves[501], leaves[-1]):                 # three leaves without any observation
+        rows = topo.perm[int(topo.node_row0[i]):int(topo.node_row1[i])]
+        y_obs[rows[rows >= 0]] = np.nan
+    nobs = np.array([np.isfinite(y_obs[topo.perm[int(topo.node_row0[i]):int(topo.node_row1[i])][topo.perm[int(topo.node_row0[i]):int(topo.node_row1[i])] >= 0]]).sum() for i in leaves])
+    if frac < 0.5: assert nobs.max() <= 32 and (nobs <= 16).any() and (nobs > 16).any() and (nobs == 0).sum() >= 3      # k tiles: 0, 1, 2
+    else: assert ((nobs > 32) & (nobs <= 48)).any() and (nobs > 48).any() and (nobs == 0).sum() >= 3                     # ... 3, 4
+    spec = mt.KernelSpec(mt.KIND_MATERN32, 0.25, 1.2)
+    cs = dict(topo=topo, locs=locs, y_obs=y_obs, spec=spec, c=dict(R=2e-2))
+    pl, lik, mean, var = run_hip(hip, cs)
+    assert pl.get_option(16) == 1
+    names = [k["name"] for k in pl.kernel_stats() if k["launches"]]
+    assert any("k_predict_hi" in k for k in names)
+    pl.set_option(16, 0)                                            # the update as a product of its own
+    pl.run(True, True)
+    d, u = pl.likelihood()
+    m2, v2 = pl.predict()
+    assert abs(d + u - lik) <= 1e-13 * abs(lik)
+    assert np.max(np.abs(m2 - mean)) < 1e-11 and K.rel(np.sqrt(v2), np.sqrt(var)) < 1e-11
+    pl.close()
+    ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
+    assert abs(lik - ref["lik"]) <= 1e-10 * abs(ref["lik"])
+    assert np.max(np.abs(mean - ref["mean"])) < 1e-9
+    assert K.rel(np.sqrt(var), ref["sd"]) < 1e-8
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_geometries(hip, seed):
     """Seeded random problems away from the benchmark geometry: rectangular grids, jittered and fully

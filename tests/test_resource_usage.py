@@ -24,8 +24,11 @@ PRODUCTION = [
     r"k_gemm_nt_lds<2, 2, 0>", r"k_gemm_nt_lds<1, 2, 0>", r"k_gemm_nt<0, 2, 0>", r"k_gemm_nt<1, 2, 0>", r"k_panel_chol",
     r"k_trsm_rows2<4>", r"k_front<false>", r"k_sum_dnode", r"k_leaf_cphantom", r"k_assemble", r"k_leaf_moments",
     # shards (at most two leaves per CU) and config 5
-    r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
+    r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4, true>", r"k_predict_hi<4, false>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
     r"k_predict_cascade<2, 6, 4, true, 3>", r"k_predict_cascade<2, 6, 4, false, 3>", r"k_predict_cascade<4, 4, 8, false, 1>",
+    # (round 4: the level operands of the predictive cascades go from global memory straight into LDS - no staging registers: every
+    # instantiation is without scratch, whatever its shape)
+    r"k_predict_cascade<",
     r"k_parent_front<12>", r"k_syrk_blk<0, 0>",
 ]
 # production kernels with a known, pinned amount of scratch: (pattern, exact bytes per lane)
@@ -41,13 +44,6 @@ ALLOWED = [
     # one-launch prior level at three workgroups per CU (168 registers; two are slower: 26.1 vs 25.4 ms at config 5): row pointers
     # and lane offsets of the epilogue are parked in scratch across the K loop (ISA: no scratch access inside the loop of 32 MFMAs)
     (r"k_leaf_gemm<2, \d, [012], 2, 4, 256, 3, 1>", 64, "epilogue addresses parked across the K loop"),
-    # dominant kernel at three workgroups per CU (168 registers): the staging registers of the NEXT level's operands are parked
-    # in scratch across the barrier between two levels (ISA: 3 x 16 B out and back per level, none inside the 8-k chunk loop of
-    # the update or between the MFMAs of a level); two workgroups per CU need none and are 8 % slower
-    (r"k_predict_cascade<2, 8, 8, (true|false), 1>", 72, "eight row tiles per workgroup at 7-8 levels: not launched (cascade_wpw = 4)"),
-    # instantiations no benchmark configuration launches (CWT = 4 cascades of shallow wide trees, 8-level CWT = 2 with update)
-    (r"k_predict_cascade<4, 4, \d, (true|false), \d>", 600, "not launched by C1-C5; superseded by the two-group cascade for r0 = 64"),
-    (r"k_predict_cascade<2, 8, 4, true, 2>", 24, "7-8 level CWT = 2 trees only"),
     (r"k_prior_cascade<4, 4, \d, \d, true>", 40, "CWT = 4 trees with <= 4 levels only"),
 ]
 
