@@ -3006,11 +3006,28 @@ _Pragma("unroll") \
                         const int coloff = is_tri ? kbt * 16 : jbz * 16; \
                         const char* sbF = (const char*)(Fs + rowoff * ls.ld + coloff); \
                         const char* sbI = (const char*)(invs + (long)(is_inv ? tile - NTRI : 0) * 256); \
-                        gld_lds16((is_inv ? sbI : sbF) + (is_inv ? vi : vz), lb_ + (long)tl * 2048); \
+                        if (GLDS & 1) gld_lds16((is_inv ? sbI : sbF) + (is_inv ? vi : vz), lb_ + (long)tl * 2048); \
+                        else pre[i] = *(const d2*)((is_inv ? sbI : sbF) + (is_inv ? vi : vz)); \
                     } \
                 } \
 } while (0)
-template <int CWT, int NLMAX, int WPW, bool UPD, int MINB>
+// the requested range has landed: DMA requests are waited for; the register-staged form (GLDS = false: one or two workgroups per
+// CU, where the LDS DMA measured slower - 0.132 against 0.118 ms for the cascade of an 8-way shard of C3) writes its pieces now.
+// Either way the barrier that follows publishes the range.
+#define MRA_PRED_LAND_RANGE(CNT, T0) do { \
+                if (GLDS & 1) mra_wait_vm0(); \
+                else { \
+                    const int cnt_ = (CNT); \
+                    char* const lb_ = (char*)lds + (long)(T0) * 2048 + whalf * 1024 + (long)lane * 16; \
+_Pragma("unroll") \
+                    for (int i = 0; i < PH; ++i) { \
+                        const int tl = i * TPS + wv; \
+                        if (i * TPS < cnt_ && tl < cnt_) *(d2*)(lb_ + (long)tl * 2048) = pre[i]; \
+                    } \
+                } \
+} while (0)
+// GLDS: bit 0 - the level operands by LDS DMA (else through registers), bit 1 - the Ut chunks of the leaf update
+template <int CWT, int NLMAX, int WPW, bool UPD, int MINB, int GLDS = 3>
 __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int CW = CWT * 16;
@@ -3019,6 +3036,7 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
     // staging steps of HALF a level's operand tiles (see MRA_PRED_LOAD_RANGE)
     constexpr int PH = pred_half_steps<CWT, NLMAX, NTH>();
     constexpr int TPS = NTH / 128;                            // tiles the workgroup moves per staging step
+    d2 pre[(GLDS & 1) ? 1 : PH];                                    // staging registers of the register-staged form
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     // staging coordinates: this thread's piece of a tile (pidx_c of 128: row prow_c, first column pcol_c) and, wave-uniform,
     // which of the TPS tiles of a step its wave works on (wv) and which half of that tile (whalf: 64 pieces = 1 KB per wave)
@@ -3077,18 +3095,28 @@ __global__ __launch_bounds__(64 * WPW, MINB) void k_predict_cascade(PredArgs ar)
             // Ut chunk staging, straight into LDS: step g moves rows g NTH/4 .. of the chunk (4 pieces per row, piece e = thread + g NTH
             // lands at byte 16 e): a scalar base per step plus ONE per-thread offset; nch is a multiple of 64, so a wave is in or out
             const unsigned uvo = (unsigned)(((int)threadIdx.x >> 2) * (int)nop + (((int)threadIdx.x & 3) << 1)) * 8u;
+            d2 sg[(GLDS & 2) ? 1 : NSTU];
 #define MRA_PRED_UT_LOADS(kcol, DST) do { \
 _Pragma("unroll") \
                 for (int g = 0; g < NSTU; ++g) { \
                     if (g * NTH + wave * 64 < nch) { \
                         const char* ub = (const char*)(ut + (long)(g * (NTH / 4)) * nop + (kcol)); \
-                        gld_lds16(ub + uvo, (char*)(DST) + (long)(g * NTH + wave * 64) * 16); \
+                        if (GLDS & 2) gld_lds16(ub + uvo, (char*)(DST) + (long)(g * NTH + wave * 64) * 16); \
+                        else sg[g] = *(const d2*)(ub + uvo); \
                     } \
+                } \
+} while (0)
+#define MRA_PRED_UT_LAND(DST) do { \
+                if (GLDS & 2) mra_wait_vm0(); \
+                else { \
+_Pragma("unroll") \
+                    for (int g = 0; g < NSTU; ++g) \
+                        if (g * NTH + wave * 64 < nch) *(d2*)((char*)(DST) + (long)(g * NTH + (int)threadIdx.x) * 16) = sg[g]; \
                 } \
 } while (0)
             MRA_PRED_UT_LOADS(0, cur);
             d2 xc = *(const d2*)tt;
-            mra_wait_vm0();
+            MRA_PRED_UT_LAND(cur);
             __syncthreads();
             MRA_PSTAMP(1);
 // one 8-k chunk: the Ut fragments of level k+1 are read while the products of level k issue, and no further ahead (left
@@ -3125,7 +3153,7 @@ _Pragma("unroll") \
                 MRA_PRED_UT_LOADS(kn, nxt);                   // (nxt was read two chunks ago: everybody has passed a barrier since)
                 const d2 xn = *(const d2*)(tt + kn);
                 MRA_PRED_UPD_CHUNK();
-                mra_wait_vm0();
+                MRA_PRED_UT_LAND(nxt);
                 __syncthreads();
                 xc = xn;
                 double* const sw = cur; cur = nxt; nxt = sw;
@@ -3146,7 +3174,7 @@ _Pragma("unroll") \
             // ---- stage: a half is requested (global -> LDS, no registers) BEFORE the products of the half in front of it, so its L2
             // round trip (a load -> ds_write loop pays ~1 us per chunk, which was half of this kernel's run time) hides behind MFMA work
             if (m == ar.nl - 1 && !pre_issued) MRA_PRED_LOAD_RANGE(m, ar.lev[m], 0, SA, 0);   // the first (deepest) level of this tree, no leaf update in front of it: LDS is untouched
-            mra_wait_vm0();
+            MRA_PRED_LAND_RANGE(SA, 0);
             __syncthreads();                                  // half A has landed, and everybody is done with the previous level's half B
             MRA_PRED_LOAD_RANGE(m, ar.lev[m], SA, TB, offb);
             if (m < 5) MRA_PSTAMP(3 + 2 * m);
@@ -3178,7 +3206,7 @@ _Pragma("unroll") \
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 if (half == 1) {
-                    mra_wait_vm0();
+                    MRA_PRED_LAND_RANGE(TB, offb);
                     __syncthreads();                          // half B has landed, and everybody is done with half A
                     if (m > 0) MRA_PRED_LOAD_RANGE(m - 1, ar.lev[m - 1], 0, (pred_sa<CWT>(m - 1)), 0);
                 }

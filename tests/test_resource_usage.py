@@ -25,9 +25,8 @@ PRODUCTION = [
     r"k_trsm_rows2<4>", r"k_front<false>", r"k_sum_dnode", r"k_leaf_cphantom", r"k_assemble", r"k_leaf_moments",
     # shards (at most two leaves per CU) and config 5
     r"k_chol_tiles<8, 4>", r"k_chol_tiles<10, 4>", r"k_predict_hi<4, true>", r"k_predict_hi<4, false>", r"k_parent_front<2>", r"k_parent_front<4>", r"k_parent_front<8>",
-    r"k_predict_cascade<2, 6, 4, true, 3>", r"k_predict_cascade<2, 6, 4, false, 3>", r"k_predict_cascade<4, 4, 8, false, 1>",
-    # (round 4: the level operands of the predictive cascades go from global memory straight into LDS - no staging registers: every
-    # instantiation is without scratch, whatever its shape)
+    r"k_predict_cascade<2, 6, 4, true, 3, 2>", r"k_predict_cascade<2, 6, 4, false, 3, 2>", r"k_predict_cascade<4, 4, 8, false, 1, 2>",
+    # (round 4: two barriers per level and the Ut chunks by LDS DMA: every instantiation is without scratch, whatever its shape)
     r"k_predict_cascade<",
     r"k_parent_front<12>", r"k_syrk_blk<0, 0>",
 ]
