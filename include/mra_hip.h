@@ -192,6 +192,15 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_UT_GATHER      13  /* 1 (default): the leaves' Ut = [W_anc[o] | y_o]^T is gathered from W by the row solve (128-byte segments); 0: scattered
                                       by the prior row cascade in 8-byte pieces (the round-2 path: 0.02 ms slower per C3 pass) */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
+#define MRA_OPT_SYRK_BLK       14  /* 1 (default): the grandparents' signed segmented SYRK of deep 64-wide trees on 96 x 96 blocks through LDS
+                                      (k_syrk_blk); 0: 32 x 32 wave tiles (k_gemm_nt) */
+#define MRA_OPT_PRIOR_LEVEL    15  /* 1 (default): level-by-level path, blocks <= 64 wide: the prior of a level in one launch (residual product,
+                                      kernel, row solve; the knots' block straight into its factor); 0: four launches per level */
+#define MRA_OPT_HI_FOLD        16  /* 1 (default): deep 64-wide trees on one GPU: the leaf update W -= Tt Ut^T inside k_predict_hi (leaves of at most
+                                      64 padded observations); 0: a product of its own over all of W; 2: inside k_predict_hi on a sharded rank too */
+#define MRA_OPT_LIK_ROWS       17  /* 1 (default): likelihood-only passes of the fused path compute the whitened basis W at the OBSERVED rows only
+                                      (gathered row tiles: a likelihood needs nothing else; W's other rows keep what an earlier pass left there);
+                                      0: at every row - what mra_get_buffer(W) callers and the node-block diagnostics want */
 int mra_plan_set_option(mra_plan *plan, int option, int64_t value);
 /* current value of an option (so that a caller can change one temporarily and put it back) */
 int mra_plan_get_option(mra_plan *plan, int option, int64_t *value);

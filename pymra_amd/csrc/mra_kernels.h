@@ -2236,6 +2236,9 @@ struct CascadeArgs {
     const int* tile_rows;     // KNOT: [ntiles][16] row numbers (-1: phantom knot)
     const int* tile_chain;    // [ntiles][8]  node slot per level
     const long* tile_row0;    // FULL: first row of each tile
+    // FULL, likelihood-only passes: the row tiles are GATHERED lists of the leaves' observed rows (16 per tile, -1: padding) -
+    // a likelihood needs W at the observed rows only (they feed Ut and C; the knots have their own pass), at C3 7 tiles of a leaf's 16
+    const int* row_gather;    // nullptr, or [ntiles][16] row numbers
     const int* tile_knot0;    // KNOT: index of the tile's first knot inside its node (multiple of 16)
     double* Wk_out;           // KNOT: [node][cw][(mlast+1)*cw] of level mlast+1
     const long* wg_tile0;     // per workgroup: first tile and number of tiles (<= 8), all sharing one chain
@@ -2435,16 +2438,16 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
     if (ar.var_out) {
         ssq += __shfl_xor(ssq, 16, 64);
         ssq += __shfl_xor(ssq, 32, 64);
-        if (q == 0) ar.var_out[myrow] = ar.cov0 - ssq;
+        if (q == 0 && !phantom_row) ar.var_out[myrow] = ar.cov0 - ssq;
     }
-    if (ar.ycol >= 0) {                 // the 16-wide y block of W: y (0 where missing) in its first column
+    if (ar.ycol >= 0 && !phantom_row) { // the 16-wide y block of W: y (0 where missing) in its first column
         const double yy = ar.y[myrow];
         const d4 yt = {(q == 0 && isfinite(yy)) ? yy : 0.0, 0.0, 0.0, 0.0};
         int qo = q;
         asm volatile("" : "+v"(qo));     // opaque: the lane part of the address is rebuilt here, not hoisted out of the tile loop and spilled
         *(d4*)(ar.W + myrow * ar.ldw + ar.ycol + 4 * qo) = yt;
     }
-    if (ar.obs_pos) {
+    if (ar.obs_pos && !phantom_row) {
         const int op = ar.obs_pos[myrow];
         if (op >= 0 && q == 0) {
             const int lf = ar.tile_leaf[t];
@@ -2459,12 +2462,13 @@ __device__ __forceinline__ void cascade_outputs(const CascadeArgs& ar, const int
 template <int CWT, int NLMAX>
 __device__ __forceinline__ double cascade_output_level(const CascadeArgs& ar, int m, long t, long myrow, int op,
                                                        const d4 (&w)[NLMAX][CWT], int q) {
+    const bool phantom_row = op == -2;                     // padding row of a gathered (likelihood-only) tile
     double* o = ar.W + myrow * ar.ldw;
     double ssq = 0.0;
 #pragma unroll
     for (int jb = 0; jb < CWT; ++jb) {
         const d4 v = w[m][jb];
-        if (!MRA_WHATIF_BIT(ar.dbg, 2)) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
+        if (!MRA_WHATIF_BIT(ar.dbg, 2) && !phantom_row) *(d4*)(o + ar.coff[m] + jb * 16 + 4 * q) = v;
         ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     if (op >= 0 && !MRA_WHATIF_BIT(ar.dbg, 1)) {
@@ -2518,8 +2522,8 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             MRA_STAMP(1);
             long myrow;
             bool phantom_row = false;
-            if (ar.knot_mode) {
-                const int rr = ar.tile_rows[t * 16 + r];
+            if (ar.knot_mode || ar.row_gather) {
+                const int rr = (ar.knot_mode ? ar.tile_rows : ar.row_gather)[t * 16 + r];
                 phantom_row = rr < 0;
                 myrow = phantom_row ? 0 : rr;
             } else {
@@ -2530,7 +2534,8 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
             for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
             d4 w[NLMAX][CWT];
             double ssq = 0.0;
-            const int op = (!ar.knot_mode && ar.obs_pos) ? ar.obs_pos[myrow] : -1;
+            // (row mode: -2 marks a padding row of a gathered tile - its outputs are skipped - without a second live register)
+            const int op = ar.knot_mode ? -1 : (phantom_row ? -2 : (ar.obs_pos ? ar.obs_pos[myrow] : -1));
 #pragma unroll
             for (int m = 0; m < NLMAX; ++m)
                 if (m <= ar.mlast) {
@@ -2539,7 +2544,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
                     if (!ar.knot_mode) ssq += cascade_output_level<CWT, NLMAX>(ar, m, t, myrow, op, w, q);
                     MRA_STAMP(3 + 2 * m);
                 }
-            cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
+            cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, ar.knot_mode ? phantom_row : op == -2, w, r, q, ssq);
             MRA_STAMP(15);
         }
     } else {
@@ -2547,8 +2552,8 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
         const long t = t0 + (active ? wave : 0);
         long myrow;
         bool phantom_row = false;
-        if (ar.knot_mode) {
-            const int rr = ar.tile_rows[t * 16 + r];
+        if (ar.knot_mode || ar.row_gather) {
+            const int rr = (ar.knot_mode ? ar.tile_rows : ar.row_gather)[t * 16 + r];
             phantom_row = rr < 0;
             myrow = phantom_row ? 0 : rr;
         } else {
@@ -2559,7 +2564,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
         for (int c = 0; c < DIM; ++c) xr[c] = ar.X[myrow * DIM + c];
         d4 w[NLMAX][CWT];
         double ssq = 0.0;
-        const int op = (!ar.knot_mode && ar.obs_pos) ? ar.obs_pos[myrow] : -1;
+        const int op = ar.knot_mode ? -1 : (phantom_row ? -2 : (ar.obs_pos ? ar.obs_pos[myrow] : -1));
 #pragma unroll
         for (int m = 0; m < NLMAX; ++m) {
             if (m <= ar.mlast) {
@@ -2572,7 +2577,7 @@ __global__ __launch_bounds__(512) void k_prior_cascade(CascadeArgs ar, KernelPar
                 }
             }
         }
-        if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, phantom_row, w, r, q, ssq);
+        if (active) cascade_outputs<CWT, NLMAX>(ar, chain, t, myrow, ar.knot_mode ? phantom_row : op == -2, w, r, q, ssq);
     }
     if (ar.knot_mode && ar.Lp_out) {
         // ---- kInv, factor and inverted diagonal blocks of every node of the workgroup, still in this launch

@@ -762,6 +762,7 @@ static void build_leaf(mra_plan* pl, const double* y) {
         }
     }, leaves_per_thread);
     pl->obs_idx.upload(obs); pl->obs_pos.upload(opos); pl->leaf_nobs.upload(nobs);
+    pl->obs_off_host = obs_off; pl->lik_tiles_valid = false;
     tr.mark("observation lists");
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
@@ -1198,6 +1199,31 @@ static bool launch_trsm2(mra_plan* pl, const Trsm2Prob* probs, size_t nprob, int
 // then ONE cascade over all leaf row tiles that writes W once
 static double kernel_cov0(const mra_plan* pl) { return pl->kp.amp; }   // C(x,x) of every stationary kernel: amp * 1
 
+// tiles of the likelihood-only row cascade: 16 observed rows each (obs_idx, padded with -1), with their leaf's ancestor chain; one
+// workgroup per leaf (or per family of sibling leaves, as the full cascade groups them)
+static void ensure_lik_tiles(mra_plan* pl) {
+    if (pl->lik_tiles_valid) return;
+    const size_t nl = pl->leaf_nodes.size();
+    std::vector<int> chains, tleaf, wgn;
+    std::vector<long> wg0;
+    for (size_t t = 0; t < nl; ++t) {
+        const int i = pl->leaf_nodes[t];
+        const long nt = (pl->obs_off_host[t + 1] - pl->obs_off_host[t]) / 16;
+        if (!nt) continue;
+        int ch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int a = pl->parent[i]; a >= 0; a = pl->parent[a]) ch[pl->node_level[a]] = pl->node_slot[a];
+        const bool join = pl->cascade_group_siblings && !wg0.empty() && t > 0 && pl->parent[i] >= 0 && pl->parent[i] == pl->parent[pl->leaf_nodes[t - 1]] &&
+                          wg0.back() + wgn.back() == pl->obs_off_host[t] / 16;
+        if (join) wgn.back() += (int)nt;
+        else { wg0.push_back(pl->obs_off_host[t] / 16); wgn.push_back((int)nt); }
+        for (long k = 0; k < nt; ++k) { tleaf.push_back((int)t); for (int c = 0; c < 8; ++c) chains.push_back(ch[c]); }
+    }
+    // (tile numbers are positions in obs_idx / 16: leaves without observations own no tile, so the per-tile arrays are dense)
+    pl->n_lik_tiles = (long)tleaf.size(); pl->n_lik_wg = (long)wg0.size();
+    pl->lik_chain.upload(chains); pl->lik_leaf.upload(tleaf); pl->lik_wg0.upload(wg0); pl->lik_wgn.upload(wgn);
+    pl->lik_tiles_valid = true;
+}
+
 static void run_prior_fused(mra_plan* pl) {
     const int cw = pl->cw[0];
     CascadeArgs base{};
@@ -1246,6 +1272,15 @@ static void run_prior_fused(mra_plan* pl) {
         for (int m = 0; m < pl->NL; ++m) fl += pl->lev[m].fl_resid + pl->lev[m].fl_trsm;
         // one pass: coordinates and y in, W (all levels + y block) and the prior variance out, observed rows once more into Ut
         fl.bytes = 8.0 * pl->P * (pl->d + 1 + pl->ldw + 1) + pl->by_leaf_ut;
+        // a likelihood needs W at the OBSERVED rows only (Ut and the leaves' C = v(o,o) + R I are built from them; the knots had their
+        // own pass): the cascade then walks gathered tiles of observed rows - 7 of a leaf's 16 tiles at C3
+        const bool lik_rows = !(pl->run_flags & MRA_RUN_PREDICT) && pl->use_lik_rows && pl->cascade_stage_all && pl->gemm_lds &&
+                              pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0 && !pl->obs_off_host.empty() && pl->obs_off_host.back() > 0;
+        if (lik_rows) {
+            ensure_lik_tiles(pl);
+            const double share = 16.0 * (double)pl->n_lik_tiles / (double)std::max<long>(pl->P, 1);
+            fl.alg *= share; fl.exec *= share; fl.bytes = share * 8.0 * pl->P * (pl->d + 1 + pl->ldw) + pl->by_leaf_ut;
+        }
         KTimer kt(pl, KF_PRIOR_TRSM, fl);
         CascadeArgs ar = base;
         ar.knot_mode = 0; ar.mlast = pl->NL - 1; ar.dbg = pl->dbg;
@@ -1265,6 +1300,11 @@ static void run_prior_fused(mra_plan* pl) {
         if (pl->cascade_stage_all) { ar.n_wg = pl->n_fwg_leaf; ar.wg_tile0 = pl->ft_wg0_leaf.p; ar.wg_ntiles = pl->ft_wgn_leaf.p; }
         else { ar.n_wg = pl->n_fwg; ar.wg_tile0 = pl->ft_wg0.p; ar.wg_ntiles = pl->ft_wgn.p; }
         ar.tile_row0 = pl->ft_row0.p; ar.tile_chain = pl->ft_chain.p;
+        if (lik_rows) {
+            ar.row_gather = pl->obs_idx.p; ar.tile_chain = pl->lik_chain.p; ar.tile_leaf = pl->lik_leaf.p;
+            ar.n_wg = pl->n_lik_wg; ar.wg_tile0 = pl->lik_wg0.p; ar.wg_ntiles = pl->lik_wgn.p;
+            ar.var_out = nullptr;                          // the prior variance is the predictive pass's (the y block stays: Ut's y row is gathered from it)
+        }
         launch_cascade_any(pl, ar);
     }
 }
@@ -2312,6 +2352,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 14) { pl->use_syrk_blk = value != 0; return MRA_OK; }
     if (option == 15) { pl->use_prior_level = value != 0; return MRA_OK; }
     if (option == 16) { pl->use_hi_fold = (int)value; return MRA_OK; }
+    if (option == 17) { pl->use_lik_rows = value != 0; return MRA_OK; }
     if (option == 13) { pl->ut_gather = value != 0; return MRA_OK; }
     if (option == 99) {
         // kernel-shape switches for A/B runs.  Bits 8 and 32 keep the results (predictive cascade at two workgroups per CU, the
@@ -2345,6 +2386,7 @@ int mra_plan_get_option(mra_plan* pl, int option, int64_t* value) {
         case 14: *value = pl->use_syrk_blk; break;
         case 15: *value = pl->use_prior_level; break;
         case 16: *value = pl->use_hi_fold; break;
+        case 17: *value = pl->use_lik_rows; break;
         case 13: *value = pl->ut_gather; break;
         case 99: *value = pl->dbg; break;
         default: return fail(pl, MraError(MRA_ERR_INVALID, "unknown option"));

@@ -372,6 +372,14 @@ struct mra_plan {
     DevVec<int> kc_ownmask;               // [bottom slot] bit m: the workgroup writes its level-m ancestor's results
     DevVec<double> kc_knots;              // [bottom slot][level][cw * (d + 1)] packed knots of the chain (mra_plan_set_locs)
     int cascade_wpw = 4;          // row tiles (= waves) per workgroup of the per-level cascade kernels (4 or 8; 4 measured faster)
+    // likelihood-only passes: the row cascade walks gathered tiles of the leaves' OBSERVED rows only (obs_idx is the gather list);
+    // per-tile chain / leaf and the workgroup list are built when such a pass first runs (ensure_lik_tiles)
+    DevVec<int> lik_chain, lik_leaf, lik_wgn;
+    DevVec<long> lik_wg0;
+    long n_lik_wg = 0, n_lik_tiles = 0;
+    bool lik_tiles_valid = false;
+    bool use_lik_rows = true;                 // option 17
+    std::vector<long> obs_off_host;           // [leaf + 1] offset of the leaf's list in obs_idx (multiples of 16)
     DevVec<long> ft_wg0_leaf;
     DevVec<int> ft_wgn_leaf;
     long n_fwg_leaf = 0;

@@ -69,8 +69,13 @@ def collect_node_blocks(tree, posterior: bool = True) -> List[NodeBlocks]:
     yv = np.asarray(tree.obs, dtype=np.float64).reshape(-1)
     R = float(tree.R)
     n = topo.n_nodes
-    # ---- pass 1: prior basis
-    pl.run(True, False)
+    # ---- pass 1: prior basis of EVERY row (a likelihood-only pass computes it at the observed rows only unless told otherwise)
+    was_lik_rows = pl.get_option(P.MRA_OPT_LIK_ROWS)
+    pl.set_option(P.MRA_OPT_LIK_ROWS, 0)
+    try:
+        pl.run(True, False)
+    finally:
+        pl.set_option(P.MRA_OPT_LIK_ROWS, was_lik_rows)
     Wp = pl.buffer(0).reshape(topo.P, ldw)
     dnode = None
     Lp = {}

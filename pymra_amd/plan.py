@@ -30,6 +30,10 @@ MRA_OPT_LEAF_SOLVE_SPLIT = 10
 MRA_OPT_CHOL_TILES = 11
 MRA_OPT_SEG_GEMM_LDS = 12
 MRA_OPT_UT_GATHER = 13
+MRA_OPT_SYRK_BLK = 14
+MRA_OPT_PRIOR_LEVEL = 15
+MRA_OPT_HI_FOLD = 16
+MRA_OPT_LIK_ROWS = 17
 MRA_BLOCK_W_ROWS, MRA_BLOCK_LPRIOR, MRA_BLOCK_FRONT, MRA_BLOCK_LEAF = 0, 1, 2, 3
 
 ERR_NAMES = {-1: "MRA_ERR_INVALID", -2: "MRA_ERR_HIP", -3: "MRA_ERR_NOT_SPD", -4: "MRA_ERR_STATE",

@@ -774,6 +774,13 @@ def test_random_geometries(hip, seed):
     pl.run(True, False)
     d, u = pl.likelihood()
     assert abs(d + u - lik) <= 1e-11 * max(1.0, abs(lik))
+    # ... whose row cascade walks gathered tiles of the OBSERVED rows only (option 17, the default where the cascade stages all its
+    # levels at once); every row's arithmetic is the same whichever tile it sits in: bit-identical to the pass over all rows
+    pl.set_option(17, 0)
+    pl.run(True, False)
+    d2, u2 = pl.likelihood()
+    assert (d2, u2) == (d, u)
+    pl.set_option(17, 1)
     # the level-by-level kernels on the same plan: the prior of a level in one launch (option 15, the default there) and as
     # residual product + gather + factorisation + row solve
     for one_launch in (1, 0):

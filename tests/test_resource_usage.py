@@ -44,6 +44,10 @@ ALLOWED = [
     # and lane offsets of the epilogue are parked in scratch across the K loop (ISA: no scratch access inside the loop of 32 MFMAs)
     (r"k_leaf_gemm<2, \d, [012], 2, 4, 256, 3, 1>", 64, "epilogue addresses parked across the K loop"),
     (r"k_prior_cascade<4, 4, \d, \d, true>", 40, "CWT = 4 trees with <= 4 levels only"),
+    # the 8-level row cascade sits at the 256-register limit of two waves per SIMD (253-255 in every covariance family); the row
+    # number of a gathered (likelihood-only) tile is one more live value and costs the family with the longest polynomial four
+    # registers (ISA: parked across the level loop, not inside a level's products).  The C3 instantiation (<2, 8, 2, 0, true>) has none.
+    (r"k_prior_cascade<2, 8, 2, 2, true>", 24, "gathered-tile row number at the 256-register limit"),
 ]
 
 
