@@ -124,7 +124,9 @@ int mra_get_predict(mra_plan *plan, double *mean_perm, double *var_perm);
 
 /* Diagnostics for tests (the reference exposes these as attributes of Node objects):
  * what = 0: whitened basis W (P x ldw, row-major) ; 1: per-node log-det terms (n_nodes);
- * copies min(capacity, available) doubles into out, returns the available count in *n_avail. */
+ * copies min(capacity, available) doubles into out, returns the available count in *n_avail.
+ * (W after a likelihood-only run is complete only with MRA_OPT_LIK_ROWS off: by default such a run computes W at the rows a
+ * likelihood needs - the observed rows, and the knots on the level-by-level path - and leaves the others as they were.) */
 int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int64_t *n_avail);
 
 /* Replaces: the per-node attributes the reference leaves on its Node objects - B, kInv (pyMRA/MRANode.py:384-385),
@@ -132,7 +134,7 @@ int mra_get_buffer(mra_plan *plan, int what, double *out, int64_t capacity, int6
  * pyMRA/MRATree.py:445-511; pyMRA/tests/debug-posterior.py:97-109).  The device keeps them in whitened form
  * (DESIGN.md section 3); this call copies one node's raw block, pymra_amd.diagnostics de-whitens on the host:
  *   MRA_BLOCK_W_ROWS  the node's rows of the whitened basis array W, all ldw columns (N_j x ldw).  After a
- *                     likelihood-only run: the prior W (B_k[S_j] = W[:, block k] L_k^T).  After a predict run with
+ *                     likelihood-only run (MRA_OPT_LIK_ROWS off): the prior W (B_k[S_j] = W[:, block k] L_k^T).  After a predict run with
  *                     MRA_OPT_FUSED off: block m of a level-m non-leaf node's rows holds X = BTil_j[m] (L_j Lt_j)^-T
  *                     (X X^T = BTil[m] kTil BTil[m]^T), the blocks of coarser levels hold the rows of BTil[k] L_k^-T
  *                     as the node's parent sees them.

@@ -974,12 +974,15 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
     const double* const A = pp->A; const long lda = pp->lda;
     const double* const B = pp->B; const long ldb = pp->ldb;
     const int* const idxB = pp->idxB;
+    // SOLVE: the rows of A (and of XA, C, var) may be a GATHERED list (idxA: absolute row numbers, -1: padding; A, XA, C and var are
+    // then row 0's) - likelihood-only passes of the level-by-level path walk the rows a likelihood needs (observed rows and knots)
+    const int* const idxA = SOLVE ? pp->idxA : nullptr;
     double* const C = pp->C; const long ldc = pp->ldc;
     const int zc = pp->zc;
     const d4 zero = {0, 0, 0, 0};
     constexpr int NST = (CT * 64 + NTHR - 1) / NTHR;             // 32-byte staging chunks per thread
     for (int rg = 0; rg < ntm; rg += RT * nwave) {
-        bool vr[RT];
+        bool vr[RT], rok[RT];
         long rowh[RT];
         const double* ap[RT];
         int qa = q;
@@ -989,6 +992,8 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
             const int ih = rg + wave + h * nwave;
             vr[h] = ih < ntm;
             rowh[h] = (long)(vr[h] ? ih : 0) * 16 + r;
+            rok[h] = true;
+            if (SOLVE && idxA) { const int gi = gldi(idxA + rowh[h]); rok[h] = gi >= 0; rowh[h] = gi < 0 ? 0 : gi; }
             ap[h] = A + rowh[h] * lda + 4 * qa;
         }
         for (int j0 = 0; j0 < ntn; j0 += CT) {
@@ -1117,12 +1122,12 @@ __global__ __launch_bounds__(NTHR, WPE) void k_leaf_gemm(const GemmProb* __restr
                             for (int s4 = 0; s4 < 4; ++s4) xx = mfma16(ia[s4], v[s4], xx);
                             x[jb] = xx;
                             ssq += xx[0] * xx[0] + xx[1] * xx[1] + xx[2] * xx[2] + xx[3] * xx[3];
-                            gst4(C + row * ldc + jb * 16 + 4 * qe, xx);
+                            if (rok[h]) gst4(C + row * ldc + jb * 16 + 4 * qe, xx);
                         }
                     }
                     ssq += __shfl_xor(ssq, 16, 64);
                     ssq += __shfl_xor(ssq, 32, 64);
-                    if (qe == 0 && pp->var) { double* vp = pp->var + row; gst(vp, gld(vp) - ssq); }
+                    if (qe == 0 && pp->var && rok[h]) { double* vp = pp->var + row; gst(vp, gld(vp) - ssq); }
                     continue;
                 }
 #pragma unroll

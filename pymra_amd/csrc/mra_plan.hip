@@ -762,7 +762,9 @@ static void build_leaf(mra_plan* pl, const double* y) {
         }
     }, leaves_per_thread);
     pl->obs_idx.upload(obs); pl->obs_pos.upload(opos); pl->leaf_nobs.upload(nobs);
-    pl->obs_off_host = obs_off; pl->lik_tiles_valid = false;
+    pl->obs_off_host = obs_off; pl->lik_tiles_valid = false; pl->lik_general_valid = false;
+    pl->y_finite_host.assign(pl->P, 0);
+    for (long p2 = 0; p2 < pl->P; ++p2) pl->y_finite_host[p2] = std::isfinite(y[p2]) ? 1 : 0;
     tr.mark("observation lists");
     pl->panel.alloc(std::max<long>(pl->leaf_poff.back(), 1));
     pl->leafInv.alloc(std::max<long>(pl->leaf_ioff.back(), 1));
@@ -1224,6 +1226,74 @@ static void ensure_lik_tiles(mra_plan* pl) {
     pl->lik_tiles_valid = true;
 }
 
+// Level-by-level path, likelihood-only passes: W is needed at the observed rows (Ut, C) and at the knots (the deeper levels'
+// residual products gather them) - at config 5 60 % of the rows.  The sorted list of such rows, padded to 16 with -1 where a run of
+// sibling leaves ends; a node's list is a contiguous piece of it; per level the one-launch prior problems over blocks of 512 entries.
+static bool ensure_lik_general(mra_plan* pl) {
+    if (pl->lik_general_valid) return pl->lik_general_ok;
+    pl->lik_general_valid = true;
+    pl->lik_general_ok = false;
+    const size_t nl = pl->leaf_nodes.size();
+    long covered = 0;
+    for (size_t t = 0; t < nl; ++t) {
+        const int i = pl->leaf_nodes[t];
+        if (t > 0 && pl->row0[i] != pl->row1[pl->leaf_nodes[t - 1]]) return false;        // leaves must tile the rows in order
+        covered += pl->row1[i] - pl->row0[i];
+    }
+    if (covered != pl->P || nl == 0 || pl->row0[pl->leaf_nodes[0]] != 0) return false;
+    for (int m = 0; m < pl->n_levels; ++m) if (!pl->lev[m].nodes.empty() && !pl->lev[m].prior_level_ok) return false;
+    std::vector<unsigned char> need(pl->y_finite_host);
+    for (int i = 0; i < pl->n_nodes; ++i)
+        if (!pl->leaf[i]) for (long k = pl->knot_ptr[i]; k < pl->knot_ptr[i + 1]; ++k) need[pl->knot_rows[k]] = 1;
+    std::vector<int> idx;
+    std::vector<long> off(nl + 1, 0), leaf_r0(nl);
+    idx.reserve((size_t)pl->P);
+    // (padding to 16 where a run of sibling leaves ends, not after every leaf: every non-leaf node's rows are a union of such runs,
+    // and a 64-row leaf with 38 needed rows would be padded to 48)
+    for (size_t t = 0; t < nl; ++t) {
+        const int i = pl->leaf_nodes[t];
+        leaf_r0[t] = pl->row0[i];
+        if (t > 0 && pl->parent[i] != pl->parent[pl->leaf_nodes[t - 1]]) while (idx.size() % 16) idx.push_back(-1);
+        off[t] = (long)idx.size();
+        for (long p = pl->row0[i]; p < pl->row1[i]; ++p) if (need[p]) idx.push_back((int)p);
+    }
+    while (idx.size() % 16) idx.push_back(-1);
+    off[nl] = (long)idx.size();
+    if (idx.empty()) return false;
+    pl->need_idx.upload(idx);
+    const long blk = 512;
+    for (int m = 0; m < pl->n_levels; ++m) {
+        LevelData& lv = pl->lev[m];
+        const size_t nn = lv.nodes.size();
+        if (!nn) continue;
+        std::vector<GemmProb> fz;
+        long rows_needed = 0, rows_all = 0;
+        const int Kanc = pl->Ka - lv.a0;
+        for (size_t s = 0; s < nn; ++s) {
+            const int i = lv.nodes[s];
+            const size_t t0 = (size_t)(std::lower_bound(leaf_r0.begin(), leaf_r0.end(), pl->row0[i]) - leaf_r0.begin());
+            const size_t t1 = (size_t)(std::lower_bound(leaf_r0.begin(), leaf_r0.end(), pl->row1[i]) - leaf_r0.begin());
+            const long o0 = off[t0], o1 = off[t1];
+            rows_needed += o1 - o0; rows_all += pl->row1[i] - pl->row0[i];
+            for (long b0 = o0; b0 < o1; b0 += blk) {
+                GemmProb g{};
+                g.A = pl->W.p + lv.a0; g.lda = pl->ldw;
+                g.B = pl->W.p + lv.a0; g.ldb = pl->ldw; g.idxB = pl->knot_idx.p + pl->knot_idx_off[i];
+                g.C = pl->W.p + lv.c0; g.ldc = pl->ldw;
+                g.XA = pl->X.p; g.XB = pl->X.p;
+                g.M = (int)std::min(blk, o1 - b0); g.N = lv.cw; g.K = Kanc; g.lower = 0;
+                g.idxA = pl->need_idx.p + b0;
+                g.solveL = lv.Lp.p + s * (size_t)lv.cw * lv.cw; g.solveI = lv.invP.p + s * (size_t)lv.cwt * 256; g.var = pl->var.p;
+                fz.push_back(g);
+            }
+        }
+        lv.gResidLik.upload(fz);
+        lv.lik_share = rows_all > 0 ? (double)rows_needed / (double)rows_all : 1.0;
+    }
+    pl->lik_general_ok = true;
+    return true;
+}
+
 static void run_prior_fused(mra_plan* pl) {
     const int cw = pl->cw[0];
     CascadeArgs base{};
@@ -1661,6 +1731,10 @@ static void run_all(mra_plan* pl, uint32_t flags) {
     // ---- 1. prior, top-down
     const bool fused = pl->regular && pl->use_fused && !pl->host_cov;
     if (fused) run_prior_fused(pl);
+    // likelihood-only: the one-launch prior levels walk the rows a likelihood needs (observed rows and knots) when every level takes
+    // that path and the leaf stage builds C from the gathered product (c_only below)
+    const bool lik_general = !fused && !pred && pl->use_lik_rows && pl->use_prior_level && !pl->host_cov && pl->gemm_lds &&
+                             pl->leaf_max_nop / 16 <= 12 && pl->leaf_max_nop > 0 && ensure_lik_general(pl);
     for (int m = 0; m < pl->n_levels && !fused; ++m) {
         LevelData& lv = pl->lev[m];
         const size_t nn = lv.nodes.size();
@@ -1670,7 +1744,15 @@ static void run_all(mra_plan* pl, uint32_t flags) {
             // launch: the residual never visits HBM
             { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_knot_resid); launch_gemm<EPI_COV>(pl, lv.gKnotResid.p, nn, lv.cw, lv.cw); }
             { KTimer kt(pl, KF_PRIOR_CHOL, lv.fl_pchol); launch_panel(pl, lv.gPriorChol.p, nn); }
-            { KTimer kt(pl, KF_PRIOR_RESID, lv.fl_resid + lv.fl_trsm.with_bytes(0.0)); mra_launch_prior_level(pl, lv.gResidFused.p, lv.gResidFused.n); }
+            if (lik_general) {
+                Work w = lv.fl_resid + lv.fl_trsm.with_bytes(0.0);
+                w.alg *= lv.lik_share; w.exec *= lv.lik_share; w.bytes *= lv.lik_share;
+                KTimer kt(pl, KF_PRIOR_RESID, w);
+                mra_launch_prior_level(pl, lv.gResidLik.p, lv.gResidLik.n);
+            } else {
+                KTimer kt(pl, KF_PRIOR_RESID, lv.fl_resid + lv.fl_trsm.with_bytes(0.0));
+                mra_launch_prior_level(pl, lv.gResidFused.p, lv.gResidFused.n);
+            }
             continue;
         }
         {

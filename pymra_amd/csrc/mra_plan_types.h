@@ -211,6 +211,8 @@ struct LevelData {
     // one-launch prior of the level (k_leaf_gemm<COV, SOLVE>): the knots' residual block straight into Lp (both sides gathered through
     // the knot list), then residual + kernel + row solve on blocks of rows
     DevVec<GemmProb> gKnotResid, gResidFused;
+    DevVec<GemmProb> gResidLik;               // ... over the gathered rows a likelihood needs (ensure_lik_general)
+    double lik_share = 1.0;                   // their share of the level's rows
     bool prior_level_ok = false;
     Work fl_knot_resid;
     std::vector<GemmProb> hResid;
@@ -378,6 +380,10 @@ struct mra_plan {
     DevVec<long> lik_wg0;
     long n_lik_wg = 0, n_lik_tiles = 0;
     bool lik_tiles_valid = false;
+    // level-by-level path: the rows a likelihood needs = observed rows and knots, per leaf (padded to 16 with -1), leaves concatenated
+    DevVec<int> need_idx;
+    std::vector<unsigned char> y_finite_host; // [P] 1 where the row is observed (set_obs)
+    bool lik_general_valid = false, lik_general_ok = false;
     bool use_lik_rows = true;                 // option 17
     std::vector<long> obs_off_host;           // [leaf + 1] offset of the leaf's list in obs_idx (multiples of 16)
     DevVec<long> ft_wg0_leaf;

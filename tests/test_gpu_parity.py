@@ -871,6 +871,20 @@ def test_deep_wide_trees_two_kernel_predictive_cascade(hip, n, r, M, oracle):
     m4, v4 = pl.predict()
     assert abs(d + u - lik) <= 1e-12 * abs(lik)
     assert np.max(np.abs(m4 - mean)) < 1e-10 and K.rel(np.sqrt(v4), np.sqrt(var)) < 1e-9
+    # likelihood-only passes walk the rows a likelihood needs (observed rows and knots: option 17, the default) - same arithmetic
+    # per row, bit-identical to the pass over all rows
+    pl.set_option(15, 1)
+    pl.run(True, False)
+    dl, ul = pl.likelihood()
+    assert any("prior of a level" in k["name"] and k["launches"] for k in pl.kernel_stats())
+    pl.set_option(17, 0)
+    pl.run(True, False)
+    assert pl.likelihood() == (dl, ul)
+    assert abs(dl + ul - lik) <= 1e-12 * abs(lik)
+    pl.set_option(17, 1)
+    pl.run(True, True)                                     # and a predictive pass behind a likelihood-only one finds nothing stale
+    m5, v5 = pl.predict()
+    assert np.max(np.abs(m5 - mean)) < 1e-10 and K.rel(np.sqrt(v5), np.sqrt(var)) < 1e-9
     pl.close()
     if oracle:
         ref = run_levelwise(topo, locs, spec, y_obs, 2e-2)
