@@ -1227,38 +1227,35 @@ static void ensure_lik_tiles(mra_plan* pl) {
 }
 
 // Level-by-level path, likelihood-only passes: W is needed at the observed rows (Ut, C) and at the knots (the deeper levels'
-// residual products gather them) - at config 5 60 % of the rows.  The sorted list of such rows, padded to 16 with -1 where a run of
-// sibling leaves ends; a node's list is a contiguous piece of it; per level the one-launch prior problems over blocks of 512 entries.
+// residual products gather them) - at config 5 60 % of the rows.  The sorted list of such rows, padded to 16 with -1 wherever a
+// non-leaf node's row range starts or ends; a node's list is a contiguous piece of it; per level the one-launch prior problems over
+// blocks of 512 entries.
 static bool ensure_lik_general(mra_plan* pl) {
     if (pl->lik_general_valid) return pl->lik_general_ok;
     pl->lik_general_valid = true;
     pl->lik_general_ok = false;
-    const size_t nl = pl->leaf_nodes.size();
-    long covered = 0;
-    for (size_t t = 0; t < nl; ++t) {
-        const int i = pl->leaf_nodes[t];
-        if (t > 0 && pl->row0[i] != pl->row1[pl->leaf_nodes[t - 1]]) return false;        // leaves must tile the rows in order
-        covered += pl->row1[i] - pl->row0[i];
-    }
-    if (covered != pl->P || nl == 0 || pl->row0[pl->leaf_nodes[0]] != 0) return false;
     for (int m = 0; m < pl->n_levels; ++m) if (!pl->lev[m].nodes.empty() && !pl->lev[m].prior_level_ok) return false;
     std::vector<unsigned char> need(pl->y_finite_host);
+    if ((long)need.size() != pl->P) return false;
     for (int i = 0; i < pl->n_nodes; ++i)
         if (!pl->leaf[i]) for (long k = pl->knot_ptr[i]; k < pl->knot_ptr[i + 1]; ++k) need[pl->knot_rows[k]] = 1;
+    // the list is cut (padded to 16) wherever a non-leaf node's row range starts or ends, so that every such node's rows are a
+    // contiguous, tile-aligned piece of it (regular trees: at the boundaries of the leaves' parents, every 256 rows at config 5; a
+    // 64-row leaf with 38 needed rows padded on its own would cost 48; a shard's orphan knot rows above its subtree are cut the same way)
+    std::vector<long> cuts;
+    for (int i = 0; i < pl->n_nodes; ++i) if (!pl->leaf[i]) { cuts.push_back(pl->row0[i]); cuts.push_back(pl->row1[i]); }
+    cuts.push_back(0); cuts.push_back(pl->P);
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
     std::vector<int> idx;
-    std::vector<long> off(nl + 1, 0), leaf_r0(nl);
+    std::vector<long> off(cuts.size(), 0);                   // position in idx of the first list entry at or behind row cuts[c]
     idx.reserve((size_t)pl->P);
-    // (padding to 16 where a run of sibling leaves ends, not after every leaf: every non-leaf node's rows are a union of such runs,
-    // and a 64-row leaf with 38 needed rows would be padded to 48)
-    for (size_t t = 0; t < nl; ++t) {
-        const int i = pl->leaf_nodes[t];
-        leaf_r0[t] = pl->row0[i];
-        if (t > 0 && pl->parent[i] != pl->parent[pl->leaf_nodes[t - 1]]) while (idx.size() % 16) idx.push_back(-1);
-        off[t] = (long)idx.size();
-        for (long p = pl->row0[i]; p < pl->row1[i]; ++p) if (need[p]) idx.push_back((int)p);
+    for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+        off[c] = (long)idx.size();
+        for (long p = cuts[c]; p < cuts[c + 1]; ++p) if (need[p]) idx.push_back((int)p);
+        while (idx.size() % 16) idx.push_back(-1);
     }
-    while (idx.size() % 16) idx.push_back(-1);
-    off[nl] = (long)idx.size();
+    off[cuts.size() - 1] = (long)idx.size();
     if (idx.empty()) return false;
     pl->need_idx.upload(idx);
     const long blk = 512;
@@ -1271,9 +1268,9 @@ static bool ensure_lik_general(mra_plan* pl) {
         const int Kanc = pl->Ka - lv.a0;
         for (size_t s = 0; s < nn; ++s) {
             const int i = lv.nodes[s];
-            const size_t t0 = (size_t)(std::lower_bound(leaf_r0.begin(), leaf_r0.end(), pl->row0[i]) - leaf_r0.begin());
-            const size_t t1 = (size_t)(std::lower_bound(leaf_r0.begin(), leaf_r0.end(), pl->row1[i]) - leaf_r0.begin());
-            const long o0 = off[t0], o1 = off[t1];
+            const size_t c0 = (size_t)(std::lower_bound(cuts.begin(), cuts.end(), pl->row0[i]) - cuts.begin());
+            const size_t c1 = (size_t)(std::lower_bound(cuts.begin(), cuts.end(), pl->row1[i]) - cuts.begin());
+            const long o0 = off[c0], o1 = off[c1];
             rows_needed += o1 - o0; rows_all += pl->row1[i] - pl->row0[i];
             for (long b0 = o0; b0 < o1; b0 += blk) {
                 GemmProb g{};
