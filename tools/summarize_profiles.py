@@ -53,7 +53,8 @@ def main():
         for r in rows:
             fam = family(r["Kernel_Name"], gs(r), mg)
             if fam is not None: fam_d[fam].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        json.dump({f: {"launches": len(v), "avg_us": sum(v) / len(v), "total_us": sum(v)} for f, v in sorted(fam_d.items())},
+        med = lambda v: sorted(v)[len(v) // 2]
+        json.dump({f: {"launches": len(v), "avg_us": sum(v) / len(v), "median_us": med(v), "min_us": min(v), "max_us": max(v), "total_us": sum(v)} for f, v in sorted(fam_d.items())},
                   open(os.path.join(dst, tag + "_kernel_family_durations.json"), "w"), indent=1)
 
     summary = {}
