@@ -790,6 +790,15 @@ def test_random_geometries(hip, seed):
         m2, v2 = pl.predict()
         assert abs(d + u - lik) <= 1e-10 * max(1.0, abs(lik)), one_launch
         assert np.max(np.abs(m2 - mean)) < 1e-9 and np.max(np.abs(np.sqrt(np.maximum(v2, 0)) - np.sqrt(np.maximum(var, 0)))) < 1e-8, one_launch
+    # ... and their likelihood-only passes over the rows a likelihood needs (observed rows and knots) against all rows: bit-identical
+    pl.set_option(15, 1)
+    liks = []
+    for rows_needed in (1, 0):
+        pl.set_option(17, rows_needed)
+        pl.run(True, False)
+        liks.append(pl.likelihood())
+    assert liks[0] == liks[1]
+    assert abs(sum(liks[0]) - lik) <= 1e-10 * max(1.0, abs(lik))
     pl.close()
 
 
