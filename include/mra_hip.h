@@ -194,8 +194,8 @@ int mra_get_timers(mra_plan *plan, double *out_ms, int capacity);
 #define MRA_OPT_UT_GATHER      13  /* 1 (default): the leaves' Ut = [W_anc[o] | y_o]^T is gathered from W by the row solve (128-byte segments); 0: scattered
                                       by the prior row cascade in 8-byte pieces (the round-2 path: 0.02 ms slower per C3 pass) */
 #define MRA_OPT_FRONT_FUSED    4   /* 1 (default): one LDS-resident launch per front level; 0: assemble / Cholesky / Schur launches */
-#define MRA_OPT_SYRK_BLK       14  /* 1 (default): the grandparents' signed segmented SYRK of deep 64-wide trees on 96 x 96 blocks through LDS
-                                      (k_syrk_blk); 0: 32 x 32 wave tiles (k_gemm_nt) */
+#define MRA_OPT_SYRK_BLK       14  /* 1 (default): the grandparents' signed segmented SYRK of deep 64-wide trees on 96 x 96 blocks through LDS,
+                                      the stage filled by LDS DMA (k_syrk_dma); 2: through registers (k_syrk_blk); 0: 32 x 32 wave tiles (k_gemm_nt) */
 #define MRA_OPT_PRIOR_LEVEL    15  /* 1 (default): level-by-level path, blocks <= 64 wide: the prior of a level in one launch (residual product,
                                       kernel, row solve; the knots' block straight into its factor); 0: four launches per level */
 #define MRA_OPT_HI_FOLD        16  /* 1 (default): deep 64-wide trees on one GPU: the leaf update W -= Tt Ut^T inside k_predict_hi (leaves of at most

@@ -919,6 +919,182 @@ __global__ __launch_bounds__(256, 2) void k_syrk_blk(const GemmProb* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+//  k_syrk_blk with the stage filled by LDS DMA (global_load_lds_dwordx4): same blocks, same deal of sub-tiles, same results.
+//  No staging registers (three workgroups per CU instead of two), no ds_write.  The DMA writes lane-linear - lane l of a wave
+//  fills 16 bytes at position l of a 1 KB piece = 8 rows of 16 doubles - so the stage cannot be padded; rows of 128 bytes all
+//  start in bank 0, and the 16-byte chunks of a row are stored XOR-swizzled instead (chunk c of row p at position c ^ (p & 7),
+//  done on the SOURCE address of the DMA): a fragment (32 bytes of a row) is read as two 16-byte halves, the eight rows a group of
+//  lanes reads fall on eight different positions.  Diagonal blocks load their rows once (both operand roles read them).  The sign
+//  of `neg` segments is applied to the A fragments as they are read.  tools/syrk_lab.hip: 12.2-12.6 ms against 12.9-13.0 for the
+//  register-staged k_syrk_blk on the same box (requesting the next stage AFTER the fragment reads instead of before them: 34 ms).
+// ------------------------------------------------------------------------------------------------
+#define SD_MAXST 128
+#ifndef SD_WPE
+#define SD_WPE 3
+#endif
+template <int EPI>
+__global__ __launch_bounds__(256, SD_WPE) void k_syrk_dma(const GemmProb* __restrict__ probs, unsigned G, unsigned nprob, unsigned S = 1) {
+    static_assert(EPI == EPI_SET, "k_syrk_dma: SET epilogue only");
+    __shared__ __attribute__((aligned(16))) double sR[2][2 * SB_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) SbStep sTab[SD_MAXST];
+    __shared__ int sNk;
+    int* const sK = (int*)&sR[0][0];                        // per-segment step counts while the table is built
+    unsigned prob_i, wg_i;
+    if (!xcd_problem_tile(G, nprob, prob_i, wg_i, S)) return;
+    const GemmProb* __restrict__ pp = probs + __builtin_amdgcn_readfirstlane(prob_i);
+    const int M = pp->M, Mt = M >> 4;
+    const int nbk = (Mt + SB_T - 1) / SB_T;
+    const int tile = __builtin_amdgcn_readfirstlane((int)wg_i);
+    if (tile >= nbk * (nbk + 1) / 2) return;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+    const int bj = tile - bi * (bi + 1) / 2;
+    const bool diag = bi == bj;
+    const int nri = min(SB_T, Mt - SB_T * bi);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    // ---- staging role: wave w moves the six 1 KB pieces 6 w .. 6 w + 5 of the 24 of a stage (piece = 8 rows; pieces 0-11 are the
+    // rows of block row bi, 12-23 those of block column bj); lane l: row l >> 3 of the piece, position l & 7, chunk (l & 7) ^ (row & 7)
+    int growi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int srow = (6 * wave + i) * 8 + (lane >> 3);                       // row of the stage
+        const int role = srow >= SB_ROWS ? 1 : 0;
+        growi[i] = min((role ? bj : bi) * SB_ROWS + srow - role * SB_ROWS, M - 1);
+    }
+    const int schunk = ((lane & 7) ^ ((lane >> 3) & 7)) * 2;                     // doubles: the logical chunk this lane fetches (rows of a piece start at a multiple of 8)
+    const GemmSeg* __restrict__ segs = pp->segs;
+    const int nseg = pp->nseg;
+    for (int sg = threadIdx.x; sg < nseg; sg += 256) sK[sg] = segs[sg].K >> 4;
+    __syncthreads();
+    for (int sg = threadIdx.x; sg < nseg; sg += 256) {
+        int start = 0;
+        for (int j = 0; j < sg; ++j) start += sK[j];
+        const int cnt = sK[sg];
+        const double* A = segs[sg].A;
+        const int lda = (int)segs[sg].lda, sgn = segs[sg].neg ? (int)0x80000000 : 0;
+        for (int t = 0; t < cnt; ++t) sTab[start + t] = SbStep{A, lda, (16 * t) | sgn};
+        if (sg == nseg - 1) sNk = start + cnt;
+    }
+    __syncthreads();                                         // (also: sK is dead before the first stage lands)
+    const int nk = __builtin_amdgcn_readfirstlane(nseg > 0 ? sNk : 0);
+    const bool loads_b = !diag;                              // diagonal blocks: both roles read the rows of role 0
+    auto request = [&](int step, int buf) {                  // DMA of step `step` into buffer `buf`
+        const SbStep e = sTab[step];
+        const double* base = e.A + (e.k0s & 0x7fffffff) + schunk;
+        char* const db = (char*)&sR[buf][0] + (long)(6 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (loads_b || 6 * wave + i < 12) gld_lds16(base + (long)growi[i] * e.lda, db + i * 1024);
+    };
+    const d4 zero = {0, 0, 0, 0};
+    d4 acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = zero;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nvr = diag ? 0 : max(0, min(3, nri - 3 * wr));
+    int rowA = 5 - wave, nA = 6 - wave, rowB = wave == 2 ? 0 : 1, nB = wave < 2 ? 0 : wave - 1;
+    if (!diag || rowA >= nri) nA = 0;
+    if (!diag || rowB >= nri) nB = 0;
+    // fragment of lane (r, q) in a 16-row sub-tile: row r, doubles 4 q .. 4 q + 3 = chunks 2 q, 2 q + 1 at their swizzled positions
+    const int fo0 = r * 16 + (((2 * q) ^ (r & 7)) << 1), fo1 = r * 16 + (((2 * q + 1) ^ (r & 7)) << 1);
+    auto frag = [&](const double* sub) -> d4 {
+        const d2 lo = *(const d2*)(sub + fo0), hi = *(const d2*)(sub + fo1);
+        return d4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    auto flip = [&](const d4 v, int sgn) -> d4 {
+        d4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __hiloint2double(__double2hiint(v[e]) ^ sgn, __double2loint(v[e]));
+        return o;
+    };
+    auto kloop = [&](auto on_diag) {
+        constexpr bool DG = decltype(on_diag)::value;
+        request(0, 0);
+        mra_wait_vm0();
+        __syncthreads();
+        for (int ks = 0; ks < nk; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < nk) request(ks + 1, cur ^ 1);       // (that buffer was read in step ks - 1: everybody has passed a barrier since)
+            const int sgn = sTab[ks].k0s & (int)0x80000000;
+            const double* sA = &sR[cur][0];
+            const double* sB = DG ? sA : sA + SB_ROWS * 16;
+            if (!DG) {
+                if (nvr > 0) {
+                    d4 a[3], b[3];
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) {
+                        a[x] = flip(frag(sA + (3 * wr + x) * 256), sgn);
+                        b[x] = frag(sB + (3 * wc + x) * 256);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int x = 0; x < 3; ++x)
+                            if (x < nvr) {
+#pragma unroll
+                                for (int y = 0; y < 3; ++y) acc[3 * x + y] = mfma16(a[x][j], b[y][j], acc[3 * x + y]);
+                            }
+                }
+            } else if ((nA | nB) != 0) {
+                const d4 aA = flip(frag(sA + rowA * 256), sgn);
+                const d4 aB = flip(frag(sA + rowB * 256), sgn);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 0 || 3 < nA) {
+                        d4 b[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) b[c] = frag(sB + (3 * h + c) * 256);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                if (3 * h + c < nA) acc[3 * h + c] = mfma16(aA[j], b[c][j], acc[3 * h + c]);
+                            if (h == 0) {
+#pragma unroll
+                                for (int c = 0; c < 2; ++c)
+                                    if (c < nB) acc[6 + c] = mfma16(aB[j], b[c][j], acc[6 + c]);
+                            }
+                        }
+                    }
+                }
+            }
+            mra_wait_vm0();
+            __syncthreads();
+        }
+    };
+    if (nk > 0) {
+        if (diag) kloop(std::true_type{});
+        else kloop(std::false_type{});
+    }
+    double* const C = pp->C;
+    const long ldc = pp->ldc;
+    const int done = pp->diag_one;
+    auto emit = [&](const d4 v, int ti, int tj) {
+        const int row0 = (SB_T * bi + ti) * 16, col = (SB_T * bj + tj) * 16 + r;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int row = row0 + q + 4 * s4;
+            gst(C + (long)row * ldc + col, v[s4] + ((row == col && row < done) ? 1.0 : 0.0));
+        }
+    };
+    if (!diag) {
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            if (x < nvr) {
+#pragma unroll
+                for (int y = 0; y < 3; ++y) emit(acc[3 * x + y], 3 * wr + x, 3 * wc + y);
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (c < nA) emit(acc[c], rowA, c);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (c < nB) emit(acc[6 + c], rowB, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 //  Leaf-resident batched product: one workgroup (8 waves) per problem, C (=|-=) f(A B^T) with
 //    * every wave owning two 16-row tiles of A (rows w and w + 8 of each group of 16 row tiles): its A fragments
 //      come straight from global memory (32 contiguous bytes per lane, nobody else needs them),

@@ -61,7 +61,7 @@ static void launch_leaf_gemm(mra_plan* pl, const GemmProb* probs, size_t nprob) 
 
 // blocked segmented SYRK (k_syrk_blk): every problem is C = [I] + sum_seg (+|-) A_seg A_seg^T with .lower set, M == N == a multiple of 16,
 // nseg > 0 and A == B in every segment
-void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M) {
+void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M, bool dma) {
     if (!nprob || M <= 0) return;
     const long nbk = (M / 16 + SB_T - 1) / SB_T;
     const unsigned gx = (unsigned)(nbk * (nbk + 1) / 2);
@@ -74,7 +74,9 @@ void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long
             gxs = (gx + S - 1) / S;
             gy *= S;
         }
-        hipLaunchKernelGGL((k_syrk_blk<EPI_SET>), dim3(gxs * (((gy + 7u) / 8u) * 8u)), dim3(256), 0, pl->stream, probs + off, gxs, gy, S);
+        // dma: the stage filled by LDS DMA (k_syrk_dma: SD_MAXST steps at most, three workgroups per CU); else through registers
+        if (dma) hipLaunchKernelGGL((k_syrk_dma<EPI_SET>), dim3(gxs * (((gy + 7u) / 8u) * 8u)), dim3(256), 0, pl->stream, probs + off, gxs, gy, S);
+        else hipLaunchKernelGGL((k_syrk_blk<EPI_SET>), dim3(gxs * (((gy + 7u) / 8u) * 8u)), dim3(256), 0, pl->stream, probs + off, gxs, gy, S);
     }
 }
 

@@ -946,11 +946,12 @@ static void build_leaf(mra_plan* pl, const double* y) {
             }
             pl->gGrandSyrk.upload(gp);
             // k_syrk_blk keeps the K steps of a problem as a table in LDS: SB_MAXST segments / 16-column steps at most
-            pl->grand_syrk_blk_ok = (lg.nf % 16) == 0;
+            pl->grand_syrk_blk_ok = pl->grand_syrk_dma_ok = (lg.nf % 16) == 0;
             for (size_t sidx = 0; sidx < lg.nodes.size() && pl->grand_syrk_blk_ok; ++sidx) {
                 long steps = 0;
                 for (int k = 0; k < gwhere[sidx].second; ++k) steps += gsegs[gwhere[sidx].first + k].K / 16;
                 if (gwhere[sidx].second == 0 || gwhere[sidx].second > SB_MAXST || steps > SB_MAXST) pl->grand_syrk_blk_ok = false;
+                if (gwhere[sidx].second == 0 || gwhere[sidx].second > SD_MAXST || steps > SD_MAXST) pl->grand_syrk_dma_ok = false;
             }
         }
         {
@@ -1547,7 +1548,7 @@ static void run_fronts_and_predict(mra_plan* pl, int m_from, bool resume) {
                 if (is_red) throw MraError(MRA_ERR_STATE, "the reduce level cannot be the level above panel-only fronts");
                 const LevelData& lg = pl->lev[m];
                 KTimer kt(pl, KF_FRONT_SCHUR, pl->fl_grand_syrk);
-                if (pl->use_syrk_blk && pl->grand_syrk_blk_ok) mra_launch_syrk_blk(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf);
+                if (pl->use_syrk_blk && pl->grand_syrk_blk_ok) mra_launch_syrk_blk(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, pl->use_syrk_blk == 1 && pl->grand_syrk_dma_ok);
                 else launch_gemm<EPI_SET>(pl, pl->gGrandSyrk.p, lg.nodes.size(), lg.nf, lg.nf, false, true);      // (64 x 64 LDS-tiled: 24.2 vs 23.7 ms at config 5)
             } else if (is_red) {
                 // (the rank-local log-det sum of everything below rides in the same launch, see the reduce block)
@@ -2428,7 +2429,7 @@ int mra_plan_set_option(mra_plan* pl, int option, int64_t value) {
     if (option == 10) { pl->leaf_solve_split = value == 2 ? 2 : 1; return MRA_OK; }
     if (option == 11) { pl->use_chol_lds = (int)value; return MRA_OK; }
     if (option == 12) { pl->seg_gemm_lds = value != 0; return MRA_OK; }
-    if (option == 14) { pl->use_syrk_blk = value != 0; return MRA_OK; }
+    if (option == 14) { pl->use_syrk_blk = (int)value; return MRA_OK; }
     if (option == 15) { pl->use_prior_level = value != 0; return MRA_OK; }
     if (option == 16) { pl->use_hi_fold = (int)value; return MRA_OK; }
     if (option == 17) { pl->use_lik_rows = value != 0; return MRA_OK; }

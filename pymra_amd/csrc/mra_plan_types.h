@@ -298,8 +298,9 @@ struct mra_plan {
     bool hi_fold_now = false;                 // ... decided for the pass that is running
     bool use_prior_level = true;              // levels of the level-by-level prior with blocks <= 64 wide: residual + kernel + row solve in one launch (option 15)
     bool parent_panel_lds_ok = false;         // every parent-panel problem fits the step table of the LDS-tiled segmented product
+    bool grand_syrk_dma_ok = false;           // ... and the smaller one of its DMA-staged form
     bool grand_syrk_blk_ok = false;           // every grandparent problem fits k_syrk_blk's step table
-    bool use_syrk_blk = true;                 // the grandparents' signed SYRK on 96 x 96 blocks through LDS (k_syrk_blk) instead of 32 x 32 wave tiles (option 14)
+    int use_syrk_blk = 1;                     // the grandparents' signed SYRK on 96 x 96 blocks through LDS (k_syrk_blk) instead of 32 x 32 wave tiles (option 14)
     bool seg_gemm_lds = true;                 // the parents' panel product (segmented: sum over the children's Ut blocks) on the LDS-tiled GEMM (6.3 -> 5.4 ms at config 5)
     bool use_pred_update = true, pred_update_now = false;   // leaf update folded into the predictive cascade
     DevVec<long> leaf_row0_dev;
@@ -428,7 +429,7 @@ static inline void ensure_big_lds(mra_plan* pl, std::initializer_list<const void
 // batched C (=|-=) f(A B^T) with epilogue EPI_SET / EPI_SUB / EPI_COV / EPI_HOSTCOV; lower_tri: every problem has .lower set and M == N
 void mra_launch_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob, long maxM, long maxN, bool allow_lds = true, bool lower_tri = false);
 void mra_launch_leaf_gemm(mra_plan* pl, int epi, const GemmProb* probs, size_t nprob);
-void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M);
+void mra_launch_syrk_blk(mra_plan* pl, const GemmProb* probs, size_t nprob, long M, bool dma);
 void mra_launch_prior_level(mra_plan* pl, const GemmProb* probs, size_t nprob);
 void launch_cascade_d1(mra_plan* pl, const CascadeArgs& ar);       // one translation unit per spatial dimension
 void launch_cascade_d2(mra_plan* pl, const CascadeArgs& ar);

@@ -864,13 +864,15 @@ def test_deep_wide_trees_two_kernel_predictive_cascade(hip, n, r, M, oracle):
     assert abs(d + u - lik) <= 1e-13 * abs(lik)
     # the grandparents' signed SYRK: 96 x 96 blocks through LDS (k_syrk_blk, the default; ragged last blocks of 5, 3 and 1 sub-tile
     # rows at these depths) against the 32 x 32 wave tiles of k_gemm_nt
-    assert pl.get_option(14) == 1
-    pl.set_option(12, 1); pl.set_option(14, 0)
-    pl.run(True, True)
-    d, u = pl.likelihood()
-    m3, v3 = pl.predict()
-    assert abs(d + u - lik) <= 1e-13 * abs(lik)
-    assert np.max(np.abs(m3 - mean)) < 1e-11 and K.rel(np.sqrt(v3), np.sqrt(var)) < 1e-10
+    assert pl.get_option(14) == 1                          # stage by LDS DMA (k_syrk_dma); 2: through registers (k_syrk_blk); 0: k_gemm_nt
+    pl.set_option(12, 1)
+    for form in (2, 0):
+        pl.set_option(14, form)
+        pl.run(True, True)
+        d, u = pl.likelihood()
+        m3, v3 = pl.predict()
+        assert abs(d + u - lik) <= 1e-13 * abs(lik), form
+        assert np.max(np.abs(m3 - mean)) < 1e-11 and K.rel(np.sqrt(v3), np.sqrt(var)) < 1e-10, form
     # the prior of a level in one launch (knots' residual block -> Lp, then residual + kernel + row solve: k_leaf_gemm<COV, SOLVE>,
     # the default) against residual product, gather, factorisation and row solve as four launches
     assert pl.get_option(15) == 1

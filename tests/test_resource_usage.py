@@ -28,7 +28,7 @@ PRODUCTION = [
     r"k_predict_cascade<2, 6, 4, true, 3, 2>", r"k_predict_cascade<2, 6, 4, false, 3, 2>", r"k_predict_cascade<4, 4, 8, false, 1, 2>",
     # (round 4: two barriers per level and the Ut chunks by LDS DMA: every instantiation is without scratch, whatever its shape)
     r"k_predict_cascade<",
-    r"k_parent_front<12>", r"k_syrk_blk<0, 0>",
+    r"k_parent_front<12>", r"k_syrk_blk<0, 0>", r"k_syrk_dma<0>",
 ]
 # production kernels with a known, pinned amount of scratch: (pattern, exact bytes per lane)
 PINNED = []      # (round 4: k_parent_front<12> lost its 36 B with the blocked factorisation atom, the predictive cascades theirs with half staging)

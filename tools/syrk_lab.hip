@@ -91,6 +91,32 @@ int main(int argc, char** argv) {
         }
         printf("max |k_syrk_blk - k_gemm_nt| over the lower sub-tiles: %.3e\n", worst);
     }
+    {
+        // the DMA-staged form: correctness against the same reference, then time
+        CK(hipMemset(dC1, 0, (size_t)nprob * M * M * 8));
+        const long nbk = (M / 16 + SB_T - 1) / SB_T;
+        const unsigned gx = (unsigned)(nbk * (nbk + 1) / 2);
+        const dim3 grid(gx * (((unsigned)nprob + 7u) / 8u) * 8u);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL((k_syrk_dma<EPI_SET>), grid, dim3(256), 0, 0, dp1, gx, (unsigned)nprob, 1u);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_syrk_dma<EPI_SET>), grid, dim3(256), 0, 0, dp1, gx, (unsigned)nprob, 1u);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<double> c0((size_t)M * M), c1((size_t)M * M);
+        double worst = 0;
+        for (int which : {0, nprob - 1}) {
+            CK(hipMemcpy(c0.data(), dC0 + (size_t)which * M * M, c0.size() * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(c1.data(), dC1 + (size_t)which * M * M, c1.size() * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < M; ++i)
+                for (int j = 0; j < M; ++j)
+                    if (j / 16 <= i / 16) worst = fmax(worst, fabs(c0[(size_t)i * M + j] - c1[(size_t)i * M + j]));
+        }
+        printf("k_syrk_dma (stage by LDS DMA, three workgroups per CU) %8.3f ms (%.3f per 4096), max |diff| %.3e\n", ms / 3, ms / 3 * 4096.0 / nprob, worst);
+    }
     t = run_blk<1>(dp1, nprob, M, 3);   printf("  without barriers                                  %8.3f ms per 4096\n", t * 4096.0 / nprob);
     t = run_blk<2>(dp1, nprob, M, 3);   printf("  without the global loads of the loop              %8.3f\n", t * 4096.0 / nprob);
     t = run_blk<8>(dp1, nprob, M, 3);   printf("  without the LDS writes of the loop                %8.3f\n", t * 4096.0 / nprob);
