@@ -287,7 +287,14 @@ def main():
     # PyTorch is rendezvous plumbing for N > 1 only (gloo barrier, broadcast of the RCCL id, max over ranks); a single-GPU run
     # never imports it: the data path is ctypes -> libmra_hip.so, and the device barrier is the library's hipDeviceSynchronize
     dist = torch = None
+    json_fd = None
     if world > 1:
+        # rank 0 prints ONE JSON line: gloo announces its connections on stdout (C++ side) when the first collective runs, so
+        # file descriptor 1 of every rank is pointed at stderr for the lifetime of the process and the line goes out through a
+        # copy of the original descriptor
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo")
@@ -510,7 +517,11 @@ def main():
         out["end_to_end"] = e2e
         out["value_end_to_end"] = e2e["value"]
     if rank == 0:
-        print(json.dumps(out))
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
