@@ -28,3 +28,7 @@ cp $(ls -t gpurun_out/prof_${TAG}_c5/*/*_kernel_stats.csv | head -1) "$P/${TAG}_
 for f in "$P/${TAG}_bench_2ranks_one_gpu_gloo_rehearsal.json" "$P/${TAG}_bench_c5_4ranks_one_gpu_gloo_rehearsal_mle.json"; do grep '^{"metric"' "$f" > "$f.tmp" && mv "$f.tmp" "$f"; done
 rm -f "$P"/*.err "$P"/*.log
 ls -la "$P"
+# SQ counters of a config-5 pass (matrix-pipe busy fraction per kernel): counters in a run of their own, the program itself behind --
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/gpurun_out/prof_${TAG}_c5sq" -- python3 tools/shard_timing.py --config c5 1 > "$P/c5_sq.log" 2>&1
+python3 tools/summarize_profiles.py --sq "$(ls -t gpurun_out/prof_${TAG}_c5sq/*/*_counter_collection.csv | head -1)" "$P/${TAG}_c5_pmc_sq_summary.json"
+rm -f "$P"/*.log

@@ -23,7 +23,29 @@ KNOT = "k_knot_chain + k_prior_cascade<KNOT> knot pass (knot rows, kInv, Cholesk
 SMALL = "small kernels (k_assemble, k_leaf_cphantom, k_sum_dnode, ...)"
 
 
+def sq_summary(csv_path, out_path):
+    """SQ counters of a --pmc pass, averaged per (kernel, grid): matrix-pipe busy fraction, shader clock, instruction mix."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(csv_path)):
+        k = r["Kernel_Name"][:60] + " | grid " + r["Grid_Size"]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, c in acc.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        if m.get("dur_us", 0) < 50:
+            continue
+        cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        m["mfma_pipe_busy_frac"] = (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0) / cyc if cyc else None
+        m["clock_GHz"] = cyc / (m["dur_us"] * 1e3) if m.get("dur_us") else None
+        out[k] = m
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--sq":       # tools/summarize_profiles.py --sq <counter_collection.csv> <out.json>
+        sq_summary(sys.argv[2], sys.argv[3])
+        return
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "gpurun_out", "profiles_" + tag)
@@ -101,21 +123,7 @@ def main():
 
     f = one("sq/*/*_counter_collection.csv")
     if f:
-        acc = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"][:60] + " | grid " + r["Grid_Size"]
-            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            acc[k]["dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-        out = {}
-        for k, c in acc.items():
-            m = {n: sum(v) / len(v) for n, v in c.items()}
-            if m.get("dur_us", 0) < 50:
-                continue
-            cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
-            m["mfma_pipe_busy_frac"] = (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0) / cyc if cyc else None
-            m["clock_GHz"] = cyc / (m["dur_us"] * 1e3) if m.get("dur_us") else None
-            out[k] = m
-        json.dump(out, open(os.path.join(dst, tag + "_pmc_sq_summary.json"), "w"), indent=1)
+        sq_summary(f, os.path.join(dst, tag + "_pmc_sq_summary.json"))
     b = os.path.join(src, "bench.json")
     if os.path.exists(b):
         shutil.copy(b, os.path.join(dst, tag + "_bench.json"))
