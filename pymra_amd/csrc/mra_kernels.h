@@ -2121,9 +2121,7 @@ __global__ __launch_bounds__(512) void k_trsm_rows2(const Trsm2Prob* __restrict_
     // ---- stage L (strictly-lower tiles, index jb(jb-1)/2+kb) and invd (after them) in LDS.
     // (Measured at C3: this 72 KB image lets ONE workgroup run per CU although 2 x 72 KB <= 160 KB; with the inverted
     // blocks read from L2 instead the image is 56 KB, two workgroups do run per CU -- and the launch is slower, 0.93 ms
-    // against 0.77: the solve moves 3.4 GB in place and sits at ~75% of what HBM streams, more waves only contend.  So does more
-    // data in flight per wave: fetching the NEXT row tile's 14 KB before the current one is solved, round 4: 1.04 -> 1.13 ms for the
-    // leaf factor + solves at C3, 0.096 -> 0.112 on an 8-way shard.)
+    // against 0.77: the solve moves 3.4 GB in place and sits at ~75% of what HBM streams, more waves only contend.)
     stage_chunks<8>(lds, (ntri + nt) * 128, [&](int e) -> const double* {
         const int tile = e >> 7, chunk = e & 127, row = chunk >> 3, c2 = (chunk & 7) << 1;
         if (tile < ntri) {
