@@ -781,6 +781,11 @@ def test_random_geometries(hip, seed):
     d2, u2 = pl.likelihood()
     assert (d2, u2) == (d, u)
     pl.set_option(17, 1)
+    pl.set_option(13, 0)                                   # ... also when the cascade scatters Ut itself instead of the row solve gathering it
+    pl.run(True, False)
+    d3, u3 = pl.likelihood()
+    assert abs(d3 + u3 - (d + u)) <= 1e-12 * max(1.0, abs(d + u))
+    pl.set_option(13, 1)
     # the level-by-level kernels on the same plan: the prior of a level in one launch (option 15, the default there) and as
     # residual product + gather + factorisation + row solve
     for one_launch in (1, 0):
